@@ -1,0 +1,171 @@
+/*
+ * lbmk — C-ABI of the MI355X (gfx950) kernels behind the LBM bridge step.
+ *
+ * The reference (nauyihsnehs/LBM) has no native layer: its hot path runs
+ * through diffusers modules and torch ops.  Each entry point below names the
+ * reference call site (file:line, relative to the reference tree) whose
+ * arithmetic it replaces.  Every function
+ *   - takes raw device pointers, sizes and a hipStream_t (passed as void*),
+ *   - never allocates, frees or synchronises,
+ *   - returns LBMK_OK or an LBMK_ERR_* code (nothing is launched on error).
+ * Activations are bf16 (raw uint16 bit patterns), channels-last (NHWC):
+ * a [B][H][W][C] tensor is also the [B*H*W][C] token matrix.
+ */
+#ifndef LBMK_H
+#define LBMK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBMK_OK 0
+#define LBMK_ERR_ARG 1      /* unsupported shape / misaligned pointer / bad enum */
+#define LBMK_ERR_LAUNCH 2   /* hipLaunch reported an error */
+
+#define LBMK_ACT_NONE 0
+#define LBMK_ACT_SILU 1
+#define LBMK_ACT_GEGLU 2    /* packed weights interleave 16 value / 16 gate columns */
+
+int lbmk_version(void);
+const char* lbmk_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Implicit GEMM on bf16 MFMA:  out[m][n] = act(alpha * sum_k A(m,k) * w[n][k]
+ *                                           + bias[n] + rowvec[b(m)][n] + residual[m][n])
+ * A(m,k) is gathered from an NHWC tensor: m -> (b, oy, ox), k -> (kh, kw, c).
+ * Replaces torch conv2d / linear under diffusers' UNet2DConditionModel and
+ * AutoencoderKL as called from src/lbm/models/unets/unet.py:127-140 and
+ * src/lbm/models/vae/autoencoderKL.py:64,116,134.  A linear layer is the
+ * KH=KW=IH=IW=OH=OW=1 case (M rows of K channels).
+ * ---------------------------------------------------------------------- */
+typedef struct lbmk_igemm_desc {
+  const void* a;        /* bf16 input, pixel p at a + (p*a_cs + a_coff) elements      */
+  const void* w;        /* bf16 packed weights [N][Kp], k = (kh*KW + kw)*Cin + c       */
+  void* out;            /* [M][ldo] bf16, or f32 when out_f32                          */
+  const float* bias;    /* [N] (or [M] when bias_per_m), may be NULL                   */
+  const void* rowvec;   /* bf16 [B][rowvec_ld], added to every row of image b, or NULL */
+  const void* residual; /* bf16 [M][ldr], or NULL                                      */
+  int32_t M, N, K, Kp;  /* K = KH*KW*Cin; Kp = row stride of w (multiple of 64, zero padded) */
+  int32_t Cin, a_cs, a_coff;
+  int32_t IH, IW, OH, OW;
+  int32_t KH, KW, stride, pad_t, pad_l;
+  int32_t up2;          /* 1: input is read through a nearest-neighbour x2 upsample    */
+  int32_t ldo, ldr, rowvec_ld;
+  int32_t act;          /* LBMK_ACT_*                                                  */
+  int32_t out_f32;
+  int32_t bias_per_m;
+  float alpha;
+  int32_t batch;        /* independent problems (grid.z); strides below in elements    */
+  int64_t sa, sw, so, sr;
+  int32_t tile;         /* -1 auto, else index into the tile table (see lbmk_igemm_tiles) */
+} lbmk_igemm_desc;
+
+int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
+/* number of tile configurations; cfg i has block tile bm[i] x bn[i] */
+int lbmk_igemm_tiles(int* bm, int* bn, int cap);
+
+/* ------------------------------------------------------------------------
+ * GroupNorm(+SiLU) over NHWC bf16.  Replaces torch.nn.GroupNorm(32, C, eps)
+ * followed by SiLU inside diffusers' ResnetBlock2D / Transformer2DModel /
+ * conv_norm_out (UNet eps 1e-5, src/lbm/inference/utils.py:132-133; VAE and
+ * transformer norm eps 1e-6).
+ * partial: float scratch of lbmk_groupnorm_scratch_floats(B, HW, C, G) floats.
+ * ---------------------------------------------------------------------- */
+int64_t lbmk_groupnorm_scratch_floats(int B, int HW, int C, int G);
+int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta,
+                   float* scratch, int B, int HW, int C, int G, float eps,
+                   int silu, void* stream);
+
+/* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock norm1/2/3, eps 1e-5). */
+int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta,
+                   int rows, int C, float eps, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Flash-style attention forward, softmax(q k^T * scale) v, no mask.
+ * Replaces F.scaled_dot_product_attention inside diffusers' AttnProcessor2_0
+ * (self-attention attn1/attn2 of BasicTransformerBlock; the reference passes
+ * encoder_hidden_states=None, src/lbm/models/unets/unet.py:98,132).
+ *   q  : bf16 [B][Nq][ldq], head h at columns h*D .. h*D+D-1 (+ q_off)
+ *   k  : bf16 [B][Nk][ldk] likewise
+ *   vt : bf16 [B][H*D][ldvt]  (V transposed: row = channel, column = key)
+ *   o  : bf16 [B][Nq][ldo]
+ * Supported D: 64.
+ * ---------------------------------------------------------------------- */
+int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
+                        int B, int H, int Nq, int Nk, int D,
+                        int ldq, int ldk, int ldvt, int ldo,
+                        int64_t sq, int64_t sk, int64_t svt, int64_t so,
+                        float scale, void* stream);
+
+/* Row softmax: f32 scores [rows][ld_in] -> bf16 probabilities [rows][ld_out]
+ * (unfused attention for the VAE mid-block: 1 head, head_dim 512). */
+int lbmk_softmax_rows(const float* s, void* p, int64_t rows, int cols,
+                      int64_t ld_in, int64_t ld_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Bridge arithmetic (src/lbm/models/lbm/lbm_model.py).
+ * All tensors are contiguous [B][per_sample] with per-sample sigma.
+ * dtype codes: 0 = bf16, 1 = f32; sigma is f32 [B].  The reference multiplies by an
+ * f32 sigma tensor, so its interpolant is f32 even for bf16 latents (out_dtype 1).
+ * ---------------------------------------------------------------------- */
+/* x_t = s*z_src + (1-s)*z + sigma_b*sqrt(s*(1-s))*eps ; rows with copy_src[b]!=0 get z_src
+ * (lbm_model.py:138-148). */
+int lbmk_bridge_interp(const void* z_src, const void* z, const void* eps,
+                       const float* sigma, const uint8_t* copy_src, void* out,
+                       int B, int64_t per_sample, float bridge_sigma, int in_dtype,
+                       int out_dtype, void* stream);
+/* x' = cast(x + (s_next - s)*pred) ; if eps: x' = cast(x' + sigma_b*sqrt(s_next*(1-s_next))*eps)
+ * (scheduler.step + re-noise, lbm_model.py:346-351). */
+int lbmk_euler_step(const void* x, const void* pred, const void* eps, void* out,
+                    int64_t n, float s, float s_next, float bridge_sigma,
+                    int dtype, void* stream);
+/* per-sample mean over per_sample elements of ((pred-tgt)*mask)^2 (l2) or abs (l1)
+ * with tgt = z_src - z  (lbm_model.py:159,186-195). mask may be NULL. out: f32 [B]. */
+int lbmk_latent_loss(const void* pred, const void* z_src, const void* z,
+                     const uint8_t* mask, float* out, int B, int64_t per_sample,
+                     int l1, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Layout / glue kernels.
+ * ---------------------------------------------------------------------- */
+/* NCHW (bf16 or f32, in_dtype 0/1) -> NHWC bf16 with channels zero-padded to Cp. */
+int lbmk_nchw_to_nhwc(const void* x, void* y, int B, int C, int H, int W, int Cp,
+                      int in_dtype, void* stream);
+/* NHWC bf16 (channel stride Cs, first C channels) -> NCHW (bf16 or f32). */
+int lbmk_nhwc_to_nchw(const void* x, void* y, int B, int C, int H, int W, int Cs,
+                      int out_dtype, void* stream);
+/* copy C channels of src (stride src_cs, offset src_off) into dst (stride dst_cs, offset dst_off);
+ * channel counts and offsets are multiples of 8 (skip-connection concat). */
+int lbmk_copy_channels(const void* src, void* dst, int64_t pixels, int C,
+                       int src_cs, int src_off, int dst_cs, int dst_off, void* stream);
+/* DiagonalGaussian sample + latent scaling (autoencoderKL.py:64-67):
+ * moments NHWC bf16 [B][HW][ms] (first 2*Cz channels = mean | logvar),
+ * z[b][c][hw] = ((mean + exp(0.5*clamp(logvar,-30,20))*eps) - shift)*scale ; eps NCHW; z NCHW.
+ * eps / z dtype: 0 bf16, 1 f32. */
+int lbmk_posterior_sample(const void* moments, const void* eps, void* z,
+                          int B, int Cz, int HW, int ms, float shift, float scale,
+                          int dtype, void* stream);
+/* sinusoidal timestep embedding, cos first (flip_sin_to_cos=True, freq_shift=0):
+ * out bf16 [B][dim]. */
+int lbmk_timestep_embedding(const float* t, void* out, int B, int dim, void* stream);
+/* y = silu(x), bf16, n multiple of 8 */
+int lbmk_silu(const void* x, void* y, int64_t n, void* stream);
+/* y = x*a + b elementwise on bf16 (n multiple of 8) — latent un-scaling before decode. */
+int lbmk_scale_shift(const void* x, void* y, int64_t n, float a, float b, void* stream);
+/* Gaussian-weighted tile accumulation (src/lbm/models/utils.py:206-258):
+ * acc[b][c][y0+y][x0+x] += tile[b][c][y][x]*wy[y]*wx[x]; wsum[y0+y][x0+x] += wy[y]*wx[x]
+ * tile: NHWC bf16 [B][th_full][tw_full][Cs] (cropped to th x tw); acc f32 NCHW [B][C][H][W]; */
+int lbmk_tile_accumulate(const void* tile, float* acc, float* wsum,
+                         const float* wy, const float* wx,
+                         int B, int C, int Cs, int th_full, int tw_full, int th, int tw,
+                         int H, int W, int y0, int x0, void* stream);
+/* out = acc / wsum  (f32 NCHW -> out dtype 0 bf16 / 1 f32) */
+int lbmk_tile_finalize(const float* acc, const float* wsum, void* out,
+                       int B, int C, int H, int W, int out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBMK_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of liblbmk.so (the C-ABI declared in include/lbmk.h).
+
+The library is built in-tree by ``make -C lbm_amd/csrc`` (or ``__graft_entry__.build()``).
+There is no fallback: importing this module without the shared library raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblbmk.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP kernels first "
+        "(`make -C lbm_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+        "lbm_amd has no CPU or eager-PyTorch fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+LBMK_OK = 0
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+DT_BF16, DT_F32 = 0, 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [
+        ("a", vp), ("w", vp), ("out", vp), ("bias", vp), ("rowvec", vp), ("residual", vp),
+        ("M", i32), ("N", i32), ("K", i32), ("Kp", i32),
+        ("Cin", i32), ("a_cs", i32), ("a_coff", i32),
+        ("IH", i32), ("IW", i32), ("OH", i32), ("OW", i32),
+        ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32),
+        ("up2", i32),
+        ("ldo", i32), ("ldr", i32), ("rowvec_ld", i32),
+        ("act", i32), ("out_f32", i32), ("bias_per_m", i32),
+        ("alpha", f32),
+        ("batch", i32),
+        ("sa", i64), ("sw", i64), ("so", i64), ("sr", i64),
+        ("tile", i32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/lbmk.h one to one
+SIGNATURES = {
+    "lbmk_version": (i32, []),
+    "lbmk_last_error": (C.c_char_p, []),
+    "lbmk_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
+    "lbmk_igemm_tiles": (i32, [C.POINTER(i32), C.POINTER(i32), i32]),
+    "lbmk_groupnorm_scratch_floats": (i64, [i32, i32, i32, i32]),
+    "lbmk_groupnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "lbmk_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "lbmk_flash_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                  i64, i64, i64, i64, f32, vp]),
+    "lbmk_softmax_rows": (i32, [vp, vp, i64, i32, i64, i64, vp]),
+    "lbmk_bridge_interp": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, i32, vp]),
+    "lbmk_euler_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, i32, vp]),
+    "lbmk_latent_loss": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "lbmk_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "lbmk_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "lbmk_copy_channels": (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "lbmk_posterior_sample": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, vp]),
+    "lbmk_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
+    "lbmk_silu": (i32, [vp, vp, i64, vp]),
+    "lbmk_scale_shift": (i32, [vp, vp, i64, f32, f32, vp]),
+    "lbmk_tile_accumulate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                   i32, i32, vp]),
+    "lbmk_tile_finalize": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here = header / library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class LbmkError(RuntimeError):
+    pass
+
+
+def check(status, what=""):
+    if status != LBMK_OK:
+        msg = lib.lbmk_last_error().decode("utf-8", "replace")
+        raise LbmkError(f"{what or 'lbmk'} failed (status {status}): {msg}")

@@ -1,0 +1,228 @@
+// Flash-style attention forward for head_dim 64 on v_mfma_f32_32x32x16_bf16 (gfx950),
+// plus the row softmax used by the unfused (head_dim 512) VAE attention.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.
+// Per 64-key tile:  S^T = K Q^T  (keys on the accumulator rows, the query row on the lane),
+// so the online-softmax statistics of a query row live in one lane pair (l, l^32) and the
+// exponentiated tile is — after a bf16 pack — directly the B operand of  O^T += V^T P^T
+// (an accumulator tile used as the next MFMA's operand, no LDS round trip for P).
+// V is consumed transposed ([channel][key]), which the projection GEMM writes for free.
+#include "common.h"
+
+__device__ __attribute__((aligned(16))) uint32_t attn_zero_page[8];
+
+namespace {
+
+constexpr int D = 64;
+constexpr int QB = 128;   // query rows per workgroup
+constexpr int KB = 64;    // keys per tile
+
+__global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
+    int64_t sk, int64_t svt, int64_t so, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * KB * 128];
+  char* sK = smem;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
+  char* sV = smem + KB * 128;    // [d][64 keys]   same image
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  Q += b * sq + head * D;
+  K += b * sk + head * D;
+  Vt += b * svt + (int64_t)head * D * ldvt;
+  O += b * so + head * D;
+
+  // Q fragments: B operand, lane (r,h) holds Q[q0+r][16ks + 8h .. +8]
+  bf16x8 qf[4];
+  {
+    const int qr = min(q0 + r, Nq - 1);
+    const bf16_t* qp = Q + (int64_t)qr * ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging coordinates: two rows per thread for each of the K and V^T images
+  const int slot = t & 7, rsub = t >> 3;
+  const int cs = slot ^ ((rsub >> 1) & 7);
+  const int rswz = (r >> 1) & 7;
+
+  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = rsub + 32 * i;
+      const int key = kv0 + row;
+      const bf16_t* src = key < Nk ? K + (int64_t)key * ldk + cs * 8 : (const bf16_t*)attn_zero_page;
+      glds16(src, sK + (wave * 8 + 32 * i) * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = rsub + 32 * i;   // channel d
+      const int key = kv0 + cs * 8;
+      const bf16_t* src = key < Nk ? Vt + (int64_t)row * ldvt + key : (const bf16_t*)attn_zero_page;
+      glds16(src, sV + (wave * 8 + 32 * i) * 128);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- S^T = K Q^T : two 32-key sub-tiles -------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+      const char* krow = sK + (32 * kt + r) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(krow + (((2 * ks + h) ^ rswz) << 4));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    if (kv0 + KB > Nk) {   // mask the keys past the end (wave-uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kv0 + 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= Nk) s[kt][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (row = lane pair (l, l^32)) -----------------------------------
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[kt][e] * scale_log2e - m_new);
+        psum += pv;
+        pf[kt][e >> 3][e & 7] = (__bf16)pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+
+    // ---- O^T += V^T P^T ------------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const char* vrow = sV + (32 * dt + r) * 128 + 8 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const int c1 = 4 * kt + 2 * ss;
+          const uint2 lo = *(const uint2*)(vrow + ((c1 ^ rswz) << 4));
+          const uint2 hi = *(const uint2*)(vrow + (((c1 + 1) ^ rswz) << 4));
+          const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, pk);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < Nq) {
+    bf16_t* op = O + (int64_t)q * ldo;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(o[dt][4 * g + e] * inv);
+        *(u16x4*)(op + 32 * dt + 8 * g + 4 * h) = ov;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,
+                                                           bf16_t* __restrict__ P, int cols,
+                                                           int64_t ld_in, int64_t ld_out) {
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* s = S + (int64_t)blockIdx.x * ld_in;
+  bf16_t* p = P + (int64_t)blockIdx.x * ld_out;
+  const int nv = cols >> 2;
+  float mx = -INFINITY;
+  for (int i = t; i < nv; i += 256) {
+    const f32x4 v = *(const f32x4*)(s + 4 * i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = t; i < nv; i += 256) {
+    const f32x4 v = *(const f32x4*)(s + 4 * i);
+    sum += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = t; i < nv; i += 256) {
+    const f32x4 v = *(const f32x4*)(s + 4 * i);
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = f2bf(__expf(v[e] - mx) * inv);
+    *(u16x4*)(p + 4 * i) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o, int B,
+                                   int H, int Nq, int Nk, int Dh, int ldq, int ldk, int ldvt,
+                                   int ldo, int64_t sq, int64_t sk, int64_t svt, int64_t so,
+                                   float scale, void* stream) {
+  LBMK_REQUIRE(q && k && vt && o, "flash_attn: null pointer");
+  LBMK_REQUIRE(Dh == 64, "flash_attn: head_dim %d not supported (64 only)", Dh);
+  LBMK_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "flash_attn: sizes");
+  LBMK_REQUIRE(Nk % 8 == 0, "flash_attn: Nk=%d must be a multiple of 8", Nk);
+  LBMK_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "flash_attn: leading dims");
+  LBMK_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && svt % 8 == 0 && so % 4 == 0, "flash_attn: batch strides");
+  LBMK_REQUIRE(ldq >= H * Dh && ldk >= H * Dh && ldo >= H * Dh && ldvt >= Nk, "flash_attn: leading dims too small");
+  LBMK_REQUIRE(lbmk_aligned(q, 16) && lbmk_aligned(k, 16) && lbmk_aligned(vt, 16) && lbmk_aligned(o, 8),
+               "flash_attn: misaligned pointer");
+  dim3 grid((Nq + QB - 1) / QB, H, B);
+  hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                     (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq,
+                     sk, svt, so, scale * 1.4426950408889634f);
+  return lbmk_check_launch("flash_attn");
+}
+
+extern "C" int lbmk_softmax_rows(const float* s, void* p, int64_t rows, int cols, int64_t ld_in,
+                                 int64_t ld_out, void* stream) {
+  LBMK_REQUIRE(s && p, "softmax_rows: null pointer");
+  LBMK_REQUIRE(rows > 0 && rows < (1LL << 31) && cols > 0 && cols % 4 == 0, "softmax_rows: rows/cols");
+  LBMK_REQUIRE(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= cols && ld_out >= cols, "softmax_rows: leading dims");
+  LBMK_REQUIRE(lbmk_aligned(s, 16) && lbmk_aligned(p, 8), "softmax_rows: misaligned");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
+                     (bf16_t*)p, cols, ld_in, ld_out);
+  return lbmk_check_launch("softmax_rows");
+}

@@ -1,0 +1,302 @@
+// Implicit-GEMM convolution / linear layer on bf16 MFMA (gfx950).
+//
+//   out[m][n] = act(alpha * sum_k A(m,k) * w[n][k] + bias + rowvec + residual)
+//
+// A(m,k) is gathered on the fly from an NHWC activation tensor (m = output pixel,
+// k = (kh, kw, c)), so a 3x3 / 1x1 / stride-2 / nearest-x2-upsampled convolution and a
+// plain linear layer are the same kernel.  Both operands are K-contiguous, so both tiles
+// are staged global -> LDS with 16-byte LDS-DMA loads (global_load_lds_dwordx4): the LDS
+// image is lane-linear, and the bank-conflict swizzle is applied on the per-lane SOURCE
+// address and again on the ds_read_b128 address.  Out-of-image taps, rows past M / N and
+// the K tail read a 16-byte zero page instead of being predicated.
+//
+// MFMA orientation: the weight fragment is the A operand and the activation fragment the
+// B operand of v_mfma_f32_16x16x32_bf16, so each lane ends up with 4 consecutive output
+// channels of one pixel (8-byte bf16 stores along the NHWC channel axis).
+#include "common.h"
+
+__device__ __attribute__((aligned(16))) uint32_t igemm_zero_page[8];
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int AI = BM / 32;                 // LDS-DMA loads per thread for the A tile
+  constexpr int BI = (BN >= 32) ? BN / 32 : 1;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128];
+  char* sA = smem;
+  char* sB = smem + BM * 128;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // XCD-aware bijective remap: blocks that share an XCD (same blockIdx % 8) get
+  // consecutive tiles, so the column tiles of one row panel hit the same L2.
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int wgid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tile_n = wgid % tiles_n;
+  const int tile_m = wgid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z * p.sw;
+
+  // ---- per-thread staging coordinates -------------------------------------------------
+  const int slot = t & 7;          // 16-byte slot inside a 128-byte LDS row
+  const int rsub = t >> 3;         // row inside a 32-row group
+  const int kk = (slot ^ ((rsub >> 1) & 7)) * 8;   // swizzled k offset inside the 64-wide tile
+  const int ohw = p.OH * p.OW;
+  const int IHe = p.up2 ? 2 * p.IH : p.IH;
+  const int IWe = p.up2 ? 2 * p.IW : p.IW;
+
+  int a_by[AI], a_bx[AI], a_boff[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + rsub + 32 * i;
+    if (m < p.M) {
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_by[i] = oy * p.stride - p.pad_t;
+      a_bx[i] = ox * p.stride - p.pad_l;
+      a_boff[i] = b * p.IH * p.IW;
+    } else {
+      a_by[i] = -(1 << 28);
+      a_bx[i] = 0;
+      a_boff[i] = 0;
+    }
+  }
+  const bf16_t* w_ptr[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int n = n0 + rsub + 32 * i;
+    w_ptr[i] = (n < p.N && (BN >= 32 || t < BN * 8)) ? W + (int64_t)n * p.Kp + kk : nullptr;
+  }
+
+  // running (tap, channel) of this thread's 8-element chunk
+  int ch = kk, tap = 0;
+  while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+  const int ntaps = p.KH * p.KW;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rd_swz = lr >> 1;   // (row >> 1) & 7 for every fragment row of this lane
+  const char* rdA = sA + (wm * WM + lr) * 128;
+  const char* rdB = sB + (wn * WN + lr) * 128;
+
+  const int nkt = p.Kp >> 6;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // ---- stage tile kt -----------------------------------------------------------------
+    {
+      int kh = 0, kw = 0;
+      if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
+      const bool tap_ok = tap < ntaps;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        int iy = a_by[i] + kh, ix = a_bx[i] + kw;
+        const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
+        if (p.up2) { iy >>= 1; ix >>= 1; }
+        const bf16_t* src = ok
+            ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
+            : (const bf16_t*)igemm_zero_page;
+        glds16(src, sA + (wave * 8 + 32 * i) * 128);
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        if (BN >= 32 || t < BN * 8) {
+          const bf16_t* src = w_ptr[i] ? w_ptr[i] + (kt << 6) : (const bf16_t*)igemm_zero_page;
+          glds16(src, sB + (wave * 8 + 32 * i) * 128);
+        }
+      }
+      ch += 64;
+      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- MFMA over the 64-deep tile ----------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int off = ((ks * 4 + lq) ^ rd_swz) << 4;
+      bf16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(rdA + i * 16 * 128 + off);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(rdB + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int64_t zo = (int64_t)z * p.so, zr = (int64_t)z * p.sr;
+  const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
+  const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
+  const bool geglu = p.act == LBMK_ACT_GEGLU;
+  const int n_out = geglu ? (p.N >> 1) : p.N;
+  const bool vec_ok = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
+                      (!res || (p.ldr & 3) == 0) && (!rowvec || (p.rowvec_ld & 3) == 0);
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WM + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int bimg = rowvec ? m / ohw : 0;
+    const float bm = (p.bias && p.bias_per_m) ? p.bias[m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int np = n0 + wn * WN + j * 16 + lq * 4;   // packed column of element 0
+      float v[4];
+      int no;                                           // output column of element 0
+      if (geglu) {
+        if (j & 1) continue;
+        if constexpr (NI >= 2) {
+          no = ((n0 + wn * WN + j * 16) >> 1) + lq * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float val = acc[i][j][e] * p.alpha, gate = acc[i][(j + 1) % NI][e] * p.alpha;
+            if (p.bias && np + 16 + e < p.N) { val += p.bias[np + e]; gate += p.bias[np + 16 + e]; }
+            v[e] = val * gelu_erf_f(gate);
+          }
+        } else {
+          continue;
+        }
+      } else {
+        no = np;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = acc[i][j][e] * p.alpha + bm;
+          if (p.bias && !p.bias_per_m && np + e < p.N) val += p.bias[np + e];
+          v[e] = val;
+        }
+      }
+      if (no >= n_out) continue;
+      if (vec_ok) {
+        if (rowvec) {
+          const u16x4 rv = *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(rv.v[e]);
+        }
+        if (res) {
+          const u16x4 rr = *(const u16x4*)(res + (int64_t)m * p.ldr + no);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(rr.v[e]);
+        }
+        if (p.act == LBMK_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+        if (p.out_f32) {
+          float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          u16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
+          *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (no + e >= n_out) break;
+          float val = v[e];
+          if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
+          if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
+          if (p.act == LBMK_ACT_SILU) val = silu_f(val);
+          if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
+          else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+namespace {
+struct TileCfg { int bm, bn; };
+const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <int BM, int BN, int WMs, int WNs>
+void launch(const lbmk_igemm_desc& d, hipStream_t s) {
+  const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs>), grid, dim3(256), 0, s, d);
+}
+}  // namespace
+
+extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
+  for (int i = 0; i < kNumTiles && i < cap; ++i) { bm[i] = kTiles[i].bm; bn[i] = kTiles[i].bn; }
+  return kNumTiles;
+}
+
+extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
+  LBMK_REQUIRE(dp != nullptr, "igemm: null descriptor");
+  lbmk_igemm_desc d = *dp;
+  LBMK_REQUIRE(d.a && d.w && d.out, "igemm: null operand");
+  LBMK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "igemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
+  LBMK_REQUIRE(d.batch >= 1 && d.batch <= 65535, "igemm: batch %d", d.batch);
+  LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
+  LBMK_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "igemm: Cin=%d must be a multiple of 8", d.Cin);
+  LBMK_REQUIRE(d.K == d.KH * d.KW * d.Cin, "igemm: K=%d != KH*KW*Cin", d.K);
+  LBMK_REQUIRE(d.Kp >= d.K && d.Kp % 64 == 0, "igemm: Kp=%d must be a multiple of 64 >= K", d.Kp);
+  LBMK_REQUIRE(d.a_cs % 8 == 0 && d.a_coff % 8 == 0 && d.a_coff >= 0 && d.a_coff + d.Cin <= d.a_cs,
+               "igemm: channel window off=%d Cin=%d stride=%d", d.a_coff, d.Cin, d.a_cs);
+  LBMK_REQUIRE(d.sa % 8 == 0 && d.sw % 8 == 0, "igemm: batch strides must keep 16-byte alignment");
+  LBMK_REQUIRE(lbmk_aligned(d.a, 16) && lbmk_aligned(d.w, 16), "igemm: a / w must be 16-byte aligned");
+  LBMK_REQUIRE(d.IH > 0 && d.IW > 0 && d.OH > 0 && d.OW > 0 && d.stride >= 1, "igemm: spatial dims");
+  LBMK_REQUIRE(d.M % (d.OH * d.OW) == 0, "igemm: M=%d is not a whole number of %dx%d images", d.M, d.OH, d.OW);
+  LBMK_REQUIRE((int64_t)(d.M / (d.OH * d.OW)) * d.IH * d.IW < (1LL << 31), "igemm: input pixel count overflows int32");
+  LBMK_REQUIRE(d.act >= 0 && d.act <= 2, "igemm: act %d", d.act);
+  LBMK_REQUIRE(d.ldo >= (d.act == LBMK_ACT_GEGLU ? d.N / 2 : d.N), "igemm: ldo=%d too small", d.ldo);
+  LBMK_REQUIRE(lbmk_aligned(d.out, d.out_f32 ? 16 : 8), "igemm: out misaligned");
+  LBMK_REQUIRE(!d.residual || lbmk_aligned(d.residual, 8), "igemm: residual misaligned");
+  LBMK_REQUIRE(!d.rowvec || lbmk_aligned(d.rowvec, 8), "igemm: rowvec misaligned");
+  LBMK_REQUIRE(!(d.bias_per_m && d.act == LBMK_ACT_GEGLU), "igemm: bias_per_m with GEGLU");
+  if (d.act == LBMK_ACT_GEGLU) {
+    LBMK_REQUIRE(d.N % 32 == 0, "igemm: GEGLU needs N %% 32 == 0 (N=%d)", d.N);
+    LBMK_REQUIRE(!d.residual && !d.rowvec && !d.out_f32, "igemm: GEGLU epilogue is bias-only, bf16");
+  }
+  if ((d.so % 4) || (d.sr % 4)) LBMK_REQUIRE(false, "igemm: so/sr must be multiples of 4");
+
+  int tile = d.tile;
+  if (tile < 0) {
+    if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
+    else {
+      const long blocks128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+      if (d.N % 128 == 0 || d.N > 1024) tile = 0;
+      else if (d.N % 64 == 0) tile = (d.M >= 65536) ? 4 : 1;
+      else tile = 0;
+      if (tile == 0 && blocks128 < 256 && d.act != LBMK_ACT_GEGLU) tile = 3;
+    }
+  }
+  LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
+  if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
+  hipStream_t s = (hipStream_t)stream;
+  switch (tile) {
+    case 0: launch<128, 128, 2, 2>(d, s); break;
+    case 1: launch<128, 64, 2, 2>(d, s); break;
+    case 2: launch<256, 16, 4, 1>(d, s); break;
+    case 3: launch<64, 64, 2, 2>(d, s); break;
+    case 4: launch<256, 64, 4, 1>(d, s); break;
+  }
+  return lbmk_check_launch("igemm");
+}

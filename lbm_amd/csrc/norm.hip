@@ -1,0 +1,258 @@
+// GroupNorm(+SiLU) and LayerNorm over channels-last bf16 activations (HBM-bound kernels).
+//
+// GroupNorm: x is [B][HW][C]; a group is C/G consecutive channels of every pixel of one
+// image.  Three launches: (1) per-slab partial sums, every thread owning one fixed 8-channel
+// chunk and striding over rows with 16-byte loads; (2) a tiny deterministic reduction of the
+// slab partials into mean / rstd; (3) apply y = x*a[c] + b[c] (+SiLU) with the same mapping.
+// No float atomics reach global memory, so results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+struct GnPlan {
+  int S;       // channel segments (grid.y); each holds whole groups
+  int nch;     // 8-channel chunks per segment
+  int rpp;     // rows handled per pass by one block
+  int nslab;   // row slabs per image (grid.x)
+  int rows_per_slab;
+};
+
+bool gn_plan(int B, int HW, int C, int G, GnPlan* pl) {
+  if (C % 8 || G <= 0 || C % G) return false;
+  int S = 1;
+  while ((C / 8 + S - 1) / S > 256 || (C / 8) % S || G % S || (C / S) % (C / G)) {
+    ++S;
+    if (S > G) return false;
+  }
+  pl->S = S;
+  pl->nch = C / 8 / S;
+  pl->rpp = 256 / pl->nch;
+  int want = (2048 + B * S - 1) / (B * S);
+  int max_slabs = (HW + pl->rpp * 8 - 1) / (pl->rpp * 8);
+  if (max_slabs < 1) max_slabs = 1;
+  int nslab = want < max_slabs ? want : max_slabs;
+  if (nslab < 1) nslab = 1;
+  pl->rows_per_slab = (HW + nslab - 1) / nslab;
+  pl->nslab = (HW + pl->rows_per_slab - 1) / pl->rows_per_slab;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x,
+                                                       float* __restrict__ partial, int HW, int C,
+                                                       int G, int nch, int rpp, int rows_per_slab,
+                                                       int nslab) {
+  __shared__ float gs[64];   // [group in segment][sum, sumsq] (<= 32 groups)
+  const int t = threadIdx.x;
+  const int slab = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
+  const int cpg = C / G;
+  const int gps = G / gridDim.y;     // groups per segment
+  const int cseg = nch * 8;          // channels per segment
+  if (t < 64) gs[t] = 0.f;
+  __syncthreads();
+  const int chunk = t % nch, rl = t / nch;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  if (rl < rpp) {
+    const int r0 = slab * rows_per_slab;
+    const int r1 = min(r0 + rows_per_slab, HW);
+    const bf16_t* base = x + ((int64_t)b * HW) * C + seg * cseg + chunk * 8;
+    for (int r = r0 + rl; r < r1; r += rpp) {
+      const u16x8 v = *(const u16x8*)(base + (int64_t)r * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f(v.v[e]);
+        s[e] += f;
+        ss[e] += f * f;
+      }
+    }
+    // fold the 8 channels into their groups (consecutive channels share a group)
+    int gprev = (chunk * 8) / cpg;
+    float as = 0.f, ass = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (chunk * 8 + e) / cpg;
+      if (g != gprev) {
+        atomicAdd(&gs[gprev * 2], as);
+        atomicAdd(&gs[gprev * 2 + 1], ass);
+        as = 0.f; ass = 0.f; gprev = g;
+      }
+      as += s[e];
+      ass += ss[e];
+    }
+    atomicAdd(&gs[gprev * 2], as);
+    atomicAdd(&gs[gprev * 2 + 1], ass);
+  }
+  __syncthreads();
+  if (t < gps * 2) {
+    const int g = seg * gps + (t >> 1);
+    partial[(((int64_t)b * G + g) * nslab + slab) * 2 + (t & 1)] = gs[t];
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                   int BG, int nslab, float inv_count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  // accumulate the slab partials in double: E[x^2]-E[x]^2 then loses nothing to the merge
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nslab; ++k) {
+    s += (double)partial[((int64_t)i * nslab + k) * 2];
+    ss += (double)partial[((int64_t)i * nslab + k) * 2 + 1];
+  }
+  const double mean = s * inv_count;
+  double var = ss * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
+                                                       bf16_t* __restrict__ y,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int HW,
+                                                       int C, int G, int nch, int rpp,
+                                                       int rows_per_slab) {
+  const int t = threadIdx.x;
+  const int slab = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
+  const int cpg = C / G;
+  const int chunk = t % nch, rl = t / nch;
+  if (rl >= rpp) return;
+  const int c0 = seg * nch * 8 + chunk * 8;
+  float a[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    const int g = c / cpg;
+    const float mean = stats[((int64_t)b * G + g) * 2], rstd = stats[((int64_t)b * G + g) * 2 + 1];
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    a[e] = rstd * ga;
+    sh[e] = be - mean * a[e];
+  }
+  const int r0 = slab * rows_per_slab;
+  const int r1 = min(r0 + rows_per_slab, HW);
+  const int64_t base = ((int64_t)b * HW) * C + c0;
+  for (int r = r0 + rl; r < r1; r += rpp) {
+    const u16x8 v = *(const u16x8*)(x + base + (int64_t)r * C);
+    u16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = bf2f(v.v[e]) * a[e] + sh[e];
+      if (SILU) f = silu_f(f);
+      o.v[e] = f2bf(f);
+    }
+    *(u16x8*)(y + base + (int64_t)r * C) = o;
+  }
+}
+
+// one wave per row; NC = 8-channel chunks per lane
+template <int NC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
+                                                        bf16_t* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int rows,
+                                                        int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunks = C >> 3;
+  float v[NC][8];
+  float s = 0.f;
+  const bf16_t* xr = x + (int64_t)row * C;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+      const u16x8 u = *(const u16x8*)(xr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(u.v[e]); s += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  bf16_t* yr = y + (int64_t)row * C;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ci = c * 8 + e;
+        const float ga = gamma ? gamma[ci] : 1.f, be = beta ? beta[ci] : 0.f;
+        o.v[e] = f2bf((v[i][e] - mean) * rstd * ga + be);
+      }
+      *(u16x8*)(yr + c * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t lbmk_groupnorm_scratch_floats(int B, int HW, int C, int G) {
+  GnPlan pl;
+  if (B <= 0 || HW <= 0 || !gn_plan(B, HW, C, G, &pl)) return -1;
+  return (int64_t)B * G * pl.nslab * 2 + (int64_t)B * G * 2;
+}
+
+extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta,
+                              float* scratch, int B, int HW, int C, int G, float eps, int silu,
+                              void* stream) {
+  LBMK_REQUIRE(x && y && scratch, "groupnorm: null pointer");
+  LBMK_REQUIRE(B > 0 && HW > 0 && B <= 65535, "groupnorm: B=%d HW=%d", B, HW);
+  GnPlan pl;
+  LBMK_REQUIRE(gn_plan(B, HW, C, G, &pl), "groupnorm: unsupported C=%d G=%d", C, G);
+  LBMK_REQUIRE(G / pl.S <= 32, "groupnorm: more than 32 groups per segment");
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16), "groupnorm: x / y must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = scratch;
+  float* stats = scratch + (int64_t)B * G * pl.nslab * 2;
+  dim3 grid(pl.nslab, pl.S, B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, partial, HW, C, G,
+                     pl.nch, pl.rpp, pl.rows_per_slab, pl.nslab);
+  const int BG = B * G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 255) / 256), dim3(256), 0, s, partial, stats, BG,
+                     pl.nslab, 1.0f / ((float)HW * (float)(C / G)), eps);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       stats, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       stats, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
+  return lbmk_check_launch("groupnorm");
+}
+
+extern "C" int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta,
+                              int rows, int C, float eps, void* stream) {
+  LBMK_REQUIRE(x && y, "layernorm: null pointer");
+  LBMK_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: rows=%d C=%d (C %% 8 == 0, <= 2048)", rows, C);
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16), "layernorm: misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4);
+  const int nc = (C / 8 + 63) / 64;
+#define LN_LAUNCH(NCV)                                                                         \
+  hipLaunchKernelGGL(layernorm_kernel<NCV>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, \
+                     gamma, beta, rows, C, eps)
+  switch (nc) {
+    case 1: LN_LAUNCH(1); break;
+    case 2: LN_LAUNCH(2); break;
+    case 3: LN_LAUNCH(3); break;
+    default: LN_LAUNCH(4); break;
+  }
+#undef LN_LAUNCH
+  return lbmk_check_launch("layernorm");
+}

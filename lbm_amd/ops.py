@@ -1,0 +1,436 @@
+"""Tensor-level wrappers over the C-ABI kernels.
+
+PyTorch is used for device memory and streams only: every function here checks its
+operands, allocates the output with ``torch.empty`` and hands raw pointers plus the
+current HIP stream to liblbmk.  Activations are bf16 channels-last: a ``[B, H, W, C]``
+tensor (contiguous) which is at the same time the ``[B*H*W, C]`` token matrix.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _C
+from ._C import ACT_GEGLU, ACT_NONE, ACT_SILU, DT_BF16, DT_F32, IgemmDesc, check, lib
+
+bf16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lbm_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise TypeError(f"unsupported dtype {t.dtype} (bf16 / f32 only)")
+
+
+def ceil_to(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------
+# weight packing (host-side, done once per module)
+# --------------------------------------------------------------------------------------
+@dataclass
+class PackedWeight:
+    w: torch.Tensor                 # bf16 [N, Kp]
+    bias: Optional[torch.Tensor]    # f32 [N] (packed order) or None
+    N: int
+    K: int
+    Kp: int
+    Cin: int                        # channels per tap after padding to a multiple of 8
+    KH: int
+    KW: int
+    geglu: bool = False
+
+
+def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
+    """[Cout, Cin, KH, KW] -> bf16 [Cout, Kp] with k = (kh*KW + kw)*Cin_p + c."""
+    N, Cin, KH, KW = weight.shape
+    cin_p = ceil_to(Cin, 8)
+    K = KH * KW * cin_p
+    Kp = ceil_to(K, 64)
+    w = torch.zeros(N, KH * KW, cin_p, dtype=bf16, device=weight.device)
+    w[:, :, :Cin] = weight.detach().permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(bf16)
+    packed = torch.zeros(N, Kp, dtype=bf16, device=weight.device)
+    packed[:, :K] = w.reshape(N, K)
+    b = None if bias is None else bias.detach().float().contiguous()
+    return PackedWeight(packed.contiguous(), b, N, K, Kp, cin_p, KH, KW)
+
+
+def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
+    """[N, K] -> bf16 [N, Kp] (K padded to a multiple of 64 with zeros)."""
+    N, K = weight.shape
+    k8 = ceil_to(K, 8)
+    Kp = ceil_to(k8, 64)
+    packed = torch.zeros(N, Kp, dtype=bf16, device=weight.device)
+    packed[:, :K] = weight.detach().to(bf16)
+    b = None if bias is None else bias.detach().float().contiguous()
+    return PackedWeight(packed, b, N, k8, Kp, k8, 1, 1)
+
+
+def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
+    """GEGLU projection [2*F, K]: rows 0..F-1 are the value half, F..2F-1 the gate half
+    (diffusers GEGLU: ``hidden, gate = proj(x).chunk(2, -1)``).  Rows are interleaved in
+    groups of 16 (16 value rows, then their 16 gate rows) so that one lane of the GEMM
+    epilogue holds a value and its gate."""
+    N2, K = weight.shape
+    F = N2 // 2
+    assert F % 16 == 0
+    idx = torch.arange(F, device=weight.device).reshape(F // 16, 16)
+    order = torch.cat([idx, idx + F], dim=1).reshape(-1)
+    pw = pack_linear_weight(weight.detach()[order], None if bias is None else bias.detach()[order])
+    pw.geglu = True
+    return pw
+
+
+# --------------------------------------------------------------------------------------
+# implicit GEMM
+# --------------------------------------------------------------------------------------
+def _igemm(desc: IgemmDesc):
+    check(lib.lbmk_igemm(C.byref(desc), _stream()), "lbmk_igemm")
+
+
+def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up2: bool = False,
+           out_hw=None, rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           act: int = ACT_NONE, cin_off: int = 0, tile: int = -1) -> torch.Tensor:
+    """x: bf16 [B, IH, IW, Cs] channels-last; reads channels [cin_off, cin_off + pw.Cin).
+    pad = (top, left); the bottom/right extent follows from out_hw (default: 'same' rule
+    (I + 2*pad - K)//stride + 1 with symmetric padding)."""
+    _need_gpu(x, pw.w)
+    assert x.dtype == bf16 and x.dim() == 4 and x.is_contiguous()
+    B, IH, IW, Cs = x.shape
+    IHe, IWe = (2 * IH, 2 * IW) if up2 else (IH, IW)
+    if out_hw is None:
+        OH = (IHe + 2 * pad[0] - pw.KH) // stride + 1
+        OW = (IWe + 2 * pad[1] - pw.KW) // stride + 1
+    else:
+        OH, OW = out_hw
+    n_out = pw.N // 2 if pw.geglu else pw.N
+    out = torch.empty(B, OH, OW, n_out, dtype=bf16, device=x.device)
+    d = IgemmDesc()
+    d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+    d.bias = _ptr(pw.bias)
+    d.rowvec = _ptr(rowvec)
+    d.residual = _ptr(residual)
+    d.M, d.N, d.K, d.Kp = B * OH * OW, pw.N, pw.K, pw.Kp
+    d.Cin, d.a_cs, d.a_coff = pw.Cin, Cs, cin_off
+    d.IH, d.IW, d.OH, d.OW = IH, IW, OH, OW
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pw.KH, pw.KW, stride, pad[0], pad[1]
+    d.up2 = 1 if up2 else 0
+    d.ldo = n_out
+    d.ldr = residual.shape[-1] if residual is not None else 0
+    d.rowvec_ld = rowvec.shape[-1] if rowvec is not None else 0
+    if residual is not None:
+        assert residual.dtype == bf16 and residual.is_contiguous() and residual.numel() == d.M * d.ldr
+    if rowvec is not None:
+        assert rowvec.dtype == bf16 and rowvec.is_contiguous() and rowvec.shape[0] == B
+    d.act = ACT_GEGLU if pw.geglu else act
+    d.out_f32, d.bias_per_m, d.alpha = 0, 0, 1.0
+    d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
+    d.tile = tile
+    _igemm(d)
+    return out
+
+
+def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor] = None,
+           rowvec: Optional[torch.Tensor] = None, rows_per_image: int = 0, act: int = ACT_NONE,
+           out: Optional[torch.Tensor] = None, tile: int = -1) -> torch.Tensor:
+    """x: bf16 [..., K] with contiguous rows (row stride = x.stride(-2)); returns [..., N]."""
+    _need_gpu(x, pw.w)
+    assert x.dtype == bf16 and x.stride(-1) == 1
+    lead = x.shape[:-1]
+    M = 1
+    for s in lead:
+        M *= s
+    Kx = x.shape[-1]
+    assert Kx == pw.K and Kx % 8 == 0, (Kx, pw.K)
+    lda = x.stride(-2) if x.dim() >= 2 else Kx
+    # all leading dims must collapse onto one row stride
+    if x.dim() > 2:
+        assert x.is_contiguous() or all(x.stride(i) == x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 2))
+    n_out = pw.N // 2 if pw.geglu else pw.N
+    if out is None:
+        out = torch.empty(*lead, n_out, dtype=bf16, device=x.device)
+    d = IgemmDesc()
+    d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+    d.bias, d.rowvec, d.residual = _ptr(pw.bias), _ptr(rowvec), _ptr(residual)
+    d.M, d.N, d.K, d.Kp = M, pw.N, pw.K, pw.Kp
+    d.Cin, d.a_cs, d.a_coff = pw.K, lda, 0
+    if rowvec is not None:
+        # rows of one image are consecutive: model them as a rows_per_image x 1 "image"
+        assert rows_per_image > 0 and M % rows_per_image == 0
+        d.IH, d.IW, d.OH, d.OW = rows_per_image, 1, rows_per_image, 1
+        d.rowvec_ld = rowvec.shape[-1]
+    else:
+        d.IH = d.IW = d.OH = d.OW = 1
+        d.rowvec_ld = 0
+    d.KH = d.KW = d.stride = 1
+    d.pad_t = d.pad_l = d.up2 = 0
+    d.ldo = out.stride(-2) if out.dim() >= 2 else n_out
+    d.ldr = residual.stride(-2) if residual is not None else 0
+    d.act = ACT_GEGLU if pw.geglu else act
+    d.out_f32 = 1 if out.dtype == torch.float32 else 0
+    d.bias_per_m, d.alpha = 0, 1.0
+    d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
+    d.tile = tile
+    _igemm(d)
+    return out
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 1.0,
+            bias_m: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, tile: int = -1) -> torch.Tensor:
+    """Batched out[z] = alpha * a[z] @ b[z]^T.  a: bf16 [Z, M, K] or [M, K]; b: bf16 [Z, N, K] or
+    [N, K]; rows contiguous, K a multiple of 64.  bias_m: f32 [M] per output row; bias_n: f32 [N]."""
+    _need_gpu(a, b)
+    assert a.dtype == bf16 and b.dtype == bf16 and a.stride(-1) == 1 and b.stride(-1) == 1
+    Z = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
+    M, K = a.shape[-2], a.shape[-1]
+    N = b.shape[-2]
+    assert b.shape[-1] == K and K % 64 == 0
+    assert b.stride(-2) == K, "b rows must be densely packed (row stride = K)"
+    shape = (Z, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
+    out = torch.empty(*shape, dtype=out_dtype, device=a.device)
+    d = IgemmDesc()
+    d.a, d.w, d.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    assert not (bias_m is not None and bias_n is not None)
+    d.bias = _ptr(bias_m if bias_m is not None else bias_n)
+    d.bias_per_m = 1 if bias_m is not None else 0
+    d.rowvec = None
+    d.residual = _ptr(residual)
+    d.M, d.N, d.K, d.Kp = M, N, K, K
+    d.Cin, d.a_cs, d.a_coff = K, a.stride(-2), 0
+    d.IH = d.IW = d.OH = d.OW = 1
+    d.KH = d.KW = d.stride = 1
+    d.pad_t = d.pad_l = d.up2 = 0
+    d.ldo, d.rowvec_ld = N, 0
+    d.ldr = residual.stride(-2) if residual is not None else 0
+    d.act, d.out_f32, d.alpha = ACT_NONE, 1 if out_dtype == torch.float32 else 0, alpha
+    d.batch = Z
+    d.sa = a.stride(0) if a.dim() == 3 else 0
+    d.sw = b.stride(0) if b.dim() == 3 else 0
+    d.so = M * N if len(shape) == 3 else 0
+    d.sr = residual.stride(0) if (residual is not None and residual.dim() == 3) else 0
+    d.tile = tile
+    _igemm(d)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------
+_gn_scratch = {}
+
+
+def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int,
+              eps: float, silu: bool) -> torch.Tensor:
+    """x: bf16 [B, H, W, C] (or [B, HW, C]); gamma/beta f32 [C]."""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    nfl = lib.lbmk_groupnorm_scratch_floats(B, HW, Cc, groups)
+    if nfl < 0:
+        raise _C.LbmkError(f"groupnorm: unsupported shape B={B} HW={HW} C={Cc} G={groups}")
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    buf = _gn_scratch.get(key)
+    if buf is None or buf.numel() < nfl:
+        buf = torch.empty(max(nfl, 1 << 16), dtype=torch.float32, device=x.device)
+        _gn_scratch[key] = buf
+    y = torch.empty_like(x)
+    check(lib.lbmk_groupnorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), buf.data_ptr(),
+                             B, HW, Cc, groups, eps, 1 if silu else 0, _stream()), "lbmk_groupnorm")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+              eps: float = 1e-5) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    check(lib.lbmk_layernorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()),
+          "lbmk_layernorm")
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, head_dim: int,
+               scale: Optional[float] = None) -> torch.Tensor:
+    """q: [B, Nq, >=H*D] (last-dim view allowed), k: [B, Nk, >=H*D], vt: [B, H*D, Nk]."""
+    _need_gpu(q, k, vt)
+    assert q.dtype == bf16 and k.dtype == bf16 and vt.dtype == bf16
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and vt.stride(-1) == 1
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    o = torch.empty(B, Nq, heads * head_dim, dtype=bf16, device=q.device)
+    check(lib.lbmk_flash_attn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, heads, Nq, Nk,
+                                  head_dim, q.stride(1), k.stride(1), vt.stride(1), o.stride(1),
+                                  q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale, _stream()),
+          "lbmk_flash_attn_fwd")
+    return o
+
+
+def softmax_rows(s: torch.Tensor) -> torch.Tensor:
+    """f32 [..., cols] -> bf16 probabilities."""
+    _need_gpu(s)
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    cols = s.shape[-1]
+    rows = s.numel() // cols
+    p = torch.empty(s.shape, dtype=bf16, device=s.device)
+    check(lib.lbmk_softmax_rows(s.data_ptr(), p.data_ptr(), rows, cols, cols, cols, _stream()), "lbmk_softmax_rows")
+    return p
+
+
+# --------------------------------------------------------------------------------------
+# bridge arithmetic
+# --------------------------------------------------------------------------------------
+def bridge_interp(z_src, z, eps, sigma, bridge_sigma: float, copy_src=None, out_dtype=torch.float32):
+    _need_gpu(z_src, z, eps, sigma)
+    assert z_src.shape == z.shape and z_src.dtype == z.dtype and z_src.is_contiguous() and z.is_contiguous()
+    if eps is not None:
+        assert eps.shape == z.shape and eps.dtype == z.dtype and eps.is_contiguous()
+    B = z.shape[0]
+    sigma = sigma.reshape(B).float().contiguous()
+    if copy_src is not None:
+        copy_src = copy_src.reshape(B).to(torch.uint8).contiguous()
+    out = torch.empty(z.shape, dtype=out_dtype, device=z.device)
+    check(lib.lbmk_bridge_interp(z_src.data_ptr(), z.data_ptr(), _ptr(eps), sigma.data_ptr(), _ptr(copy_src),
+                                 out.data_ptr(), B, z[0].numel(), float(bridge_sigma), _dt(z), _dt(out), _stream()),
+          "lbmk_bridge_interp")
+    return out
+
+
+def euler_step(x, pred, s: float, s_next: float, eps=None, bridge_sigma: float = 0.0):
+    _need_gpu(x, pred, eps)
+    assert x.shape == pred.shape and x.dtype == pred.dtype and x.is_contiguous() and pred.is_contiguous()
+    if eps is not None:
+        assert eps.shape == x.shape and eps.dtype == x.dtype and eps.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib.lbmk_euler_step(x.data_ptr(), pred.data_ptr(), _ptr(eps), out.data_ptr(), x.numel(), float(s),
+                              float(s_next), float(bridge_sigma), _dt(x), _stream()), "lbmk_euler_step")
+    return out
+
+
+def latent_loss(pred, z_src, z, mask=None, l1: bool = False):
+    _need_gpu(pred, z_src, z, mask)
+    assert pred.shape == z.shape == z_src.shape and pred.dtype == z.dtype == z_src.dtype
+    assert pred.is_contiguous() and z.is_contiguous() and z_src.is_contiguous()
+    B = z.shape[0]
+    if mask is not None:
+        mask = mask.expand_as(z).to(torch.uint8).contiguous()
+    out = torch.empty(B, dtype=torch.float32, device=z.device)
+    check(lib.lbmk_latent_loss(pred.data_ptr(), z_src.data_ptr(), z.data_ptr(), _ptr(mask), out.data_ptr(), B,
+                               z[0].numel(), 1 if l1 else 0, _dt(z), _stream()), "lbmk_latent_loss")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# layout / glue
+# --------------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
+    _need_gpu(x)
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    cp = ceil_to(Cc, 8) if cp is None else cp
+    y = torch.empty(B, H, W, cp, dtype=bf16, device=x.device)
+    check(lib.lbmk_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cc, H, W, cp, _dt(x), _stream()), "lbmk_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: int, out_dtype=bf16) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    B, H, W, Cs = x.shape
+    y = torch.empty(B, channels, H, W, dtype=out_dtype, device=x.device)
+    check(lib.lbmk_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), B, channels, H, W, Cs, _dt(y), _stream()),
+          "lbmk_nhwc_to_nchw")
+    return y
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """cat([a, b], channel axis) for channels-last bf16 tensors."""
+    _need_gpu(a, b)
+    assert a.shape[:-1] == b.shape[:-1] and a.is_contiguous() and b.is_contiguous()
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=bf16, device=a.device)
+    pixels = a.numel() // Ca
+    check(lib.lbmk_copy_channels(a.data_ptr(), out.data_ptr(), pixels, Ca, Ca, 0, Ca + Cb, 0, _stream()), "copy_channels")
+    check(lib.lbmk_copy_channels(b.data_ptr(), out.data_ptr(), pixels, Cb, Cb, 0, Ca + Cb, Ca, _stream()), "copy_channels")
+    return out
+
+
+def posterior_sample(moments: torch.Tensor, eps: torch.Tensor, cz: int, shift: float, scale: float) -> torch.Tensor:
+    """moments: bf16 NHWC [B, H, W, ms]; eps: NCHW [B, cz, H, W] (bf16 / f32) -> z NCHW, eps.dtype."""
+    _need_gpu(moments, eps)
+    assert moments.dtype == bf16 and moments.is_contiguous() and eps.is_contiguous()
+    B, H, W, ms = moments.shape
+    assert eps.shape == (B, cz, H, W)
+    z = torch.empty_like(eps)
+    check(lib.lbmk_posterior_sample(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), B, cz, H * W, ms,
+                                    float(shift), float(scale), _dt(eps), _stream()), "lbmk_posterior_sample")
+    return z
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _need_gpu(t)
+    t = t.reshape(-1).float().contiguous()
+    out = torch.empty(t.shape[0], dim, dtype=bf16, device=t.device)
+    check(lib.lbmk_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()), "timestep_embedding")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib.lbmk_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lbmk_silu")
+    return y
+
+
+def scale_shift(x: torch.Tensor, a: float, b: float) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib.lbmk_scale_shift(x.data_ptr(), y.data_ptr(), x.numel(), float(a), float(b), _stream()), "scale_shift")
+    return y
+
+
+def tile_accumulate(tile, acc, wsum, wy, wx, th, tw, y0, x0, channels):
+    _need_gpu(tile, acc, wsum, wy, wx)
+    B, thf, twf, Cs = tile.shape
+    _, Cc, H, W = acc.shape
+    assert Cc == channels and acc.dtype == torch.float32 and wsum.shape == (H, W)
+    check(lib.lbmk_tile_accumulate(tile.data_ptr(), acc.data_ptr(), wsum.data_ptr(), wy.data_ptr(), wx.data_ptr(),
+                                   B, Cc, Cs, thf, twf, th, tw, H, W, y0, x0, _stream()), "tile_accumulate")
+
+
+def tile_finalize(acc, wsum, out_dtype=torch.float32):
+    _need_gpu(acc, wsum)
+    B, Cc, H, W = acc.shape
+    out = torch.empty(B, Cc, H, W, dtype=out_dtype, device=acc.device)
+    check(lib.lbmk_tile_finalize(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), B, Cc, H, W, _dt(out), _stream()),
+          "tile_finalize")
+    return out
