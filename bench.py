@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of 1024x1024 1-NFE LBM inference (VAE encode -> one
+SDXL-style UNet evaluation + Euler step -> VAE decode), bf16, batch 16 per GPU.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; inference shards by image batch, so ranks never exchange data (the
+only collectives are the timing barrier and the max-over-ranks of the elapsed time).
+Rank 0 prints ONE JSON line.  Inputs are synthetic (uniform [-1, 1] images, seeded random
+weights of the reference's architecture: no checkpoint is available offline) and resident
+in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BF = torch.bfloat16
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
+
+
+def build_model(device, res):
+    from lbm_amd.inference.utils import sdxl_style_unet_kwargs
+    from lbm_amd.models.embedders import ConditionerWrapper
+    from lbm_amd.models.lbm import LBMConfig, LBMModel
+    from lbm_amd.models.schedulers import FlowMatchEulerDiscreteScheduler
+    from lbm_amd.models.unets import DiffusersUNet2DCondWrapper
+    from lbm_amd.models.vae import AutoencoderKL, AutoencoderKLDiffusers, AutoencoderKLDiffusersConfig
+
+    torch.manual_seed(0)
+    with torch.device(device):      # parameters are created and initialised on the GPU
+        unet = DiffusersUNet2DCondWrapper(**sdxl_style_unet_kwargs()).to(BF)
+        core = AutoencoderKL(scaling_factor=0.13025).to(BF)
+    vae = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version="synthetic", tiling_size=(128, 128)), vae_model=core)
+    cfg = LBMConfig(source_key="source_image", target_key="source_image_paste", bridge_noise_sigma=0.005,
+                    timestep_sampling="custom_timesteps", selected_timesteps=[250.0, 500.0, 750.0, 1000.0],
+                    prob=[0.25, 0.25, 0.25, 0.25])
+    model = LBMModel(cfg, denoiser=unet, sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                     training_noise_scheduler=FlowMatchEulerDiscreteScheduler(), vae=vae,
+                     conditioner=ConditionerWrapper([]))
+    model.to(device).to(BF)
+    model.eval()
+    return model
+
+
+@torch.no_grad()
+def one_step(model, images, enc_eps, nfe):
+    """One pass of the hot path over one batch: encode -> n-step bridge sampling -> decode."""
+    z = model.vae.encode(images, eps=enc_eps)
+    return model.sample(z, num_steps=nfe, conditioner_inputs={"source_image": images})
+
+
+def cpu_baseline(model, threads):
+    """The fp32 CPU oracle (a restatement of the reference's diffusers-based path, kind 'port') on a
+    bounded sample: one 512x512 image, 1 NFE (the reference's CPU-runnable configuration)."""
+    from oracle import bridge_ref as br
+    from oracle import diffusers_ref as dr
+    torch.set_num_threads(threads)
+    usd = {k: v.detach().float().cpu() for k, v in model.denoiser.state_dict().items()}
+    vsd = {k: v.detach().float().cpu() for k, v in model.vae.vae_model.state_dict().items()}
+    from lbm_amd.inference.utils import sdxl_style_unet_kwargs
+    cfg = sdxl_style_unet_kwargs()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    eps = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(4321))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        z = dr.posterior_sample(dr.vae_encode_moments(vsd, x), eps) * 0.13025
+        lat = br.sample(z, lambda s, t: dr.unet_forward(usd, cfg, s, t), 1, [], 0.005)
+        img = dr.vae_decode(vsd, lat / 0.13025)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(img).all()
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 image 512x512, 1 NFE, fp32 torch CPU oracle, {dt:.1f} s "
+                      f"(5.33 TFLOP/image; the 1024x1024 workload is 23.25 TFLOP/image, i.e. ~{dt * 23.25 / 5.33:.0f} s/image extrapolated by FLOPs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--nfe", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from lbm_amd import ops
+    model = build_model(device, args.res)
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = (torch.rand(args.batch, 3, args.res, args.res, generator=g) * 2 - 1).to(BF).to(device)
+    L = args.res // 8
+    enc_eps = torch.randn(args.batch, 4, L, L, generator=torch.Generator().manual_seed(4321 + rank)).to(BF).to(device)
+
+    for _ in range(args.warmup):
+        out = one_step(model, images, enc_eps, args.nfe)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step(model, images, enc_eps, args.nfe)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert out.shape == (args.batch, 3, args.res, args.res) and bool(torch.isfinite(out.float()).all())
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roofline, cpu = None, None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = the implicit-GEMM conv / linear kernel: every launch of one extra, untimed
+        # step is bracketed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch
+        ops.igemm_profile_begin()
+        one_step(model, images, enc_eps, args.nfe)
+        prof = ops.igemm_profile_end()
+        tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
+                    "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
+                    "flops_per_launch": prof["flops"] / prof["launches"],
+                    "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, min(16, os.cpu_count() or 1))
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        line = {
+            "metric": "images/sec (1024^2, 1-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "ms_per_image": round(elapsed / total_images * 1e3 * world, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (uniform [-1,1] images, seeded random-init weights of the reference architecture)",
+            "config": {"workload": f"LBM inference {args.res}x{args.res}, {args.nfe}-NFE, SDXL-style UNet (2.43B) + SD VAE encode/decode, "
+                                   f"batch {args.batch}/GPU, data-parallel x{world}", "global_batch": args.batch * world,
+                       "flops_per_image_T": 23.25 if (args.res, args.nfe) == (1024, 1) else None},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

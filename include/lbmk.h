@@ -42,12 +42,12 @@ const char* lbmk_last_error(void);
  * ---------------------------------------------------------------------- */
 typedef struct lbmk_igemm_desc {
   const void* a;        /* bf16 input, pixel p at a + (p*a_cs + a_coff) elements      */
-  const void* w;        /* bf16 packed weights [N][Kp], k = (kh*KW + kw)*Cin + c       */
+  const void* w;        /* bf16 weights [N] rows of stride Kp, k = (kh*KW + kw)*Cin + c */
   void* out;            /* [M][ldo] bf16, or f32 when out_f32                          */
   const float* bias;    /* [N] (or [M] when bias_per_m), may be NULL                   */
   const void* rowvec;   /* bf16 [B][rowvec_ld], added to every row of image b, or NULL */
   const void* residual; /* bf16 [M][ldr], or NULL                                      */
-  int32_t M, N, K, Kp;  /* K = KH*KW*Cin; Kp = row stride of w (multiple of 64, zero padded) */
+  int32_t M, N, K, Kp;  /* K = KH*KW*Cin; Kp = row stride of w (multiple of 8, >= K)    */
   int32_t Cin, a_cs, a_coff;
   int32_t IH, IW, OH, OW;
   int32_t KH, KW, stride, pad_t, pad_l;
@@ -125,7 +125,11 @@ int lbmk_euler_step(const void* x, const void* pred, const void* eps, void* out,
  * with tgt = z_src - z  (lbm_model.py:159,186-195). mask may be NULL. out: f32 [B]. */
 int lbmk_latent_loss(const void* pred, const void* z_src, const void* z,
                      const uint8_t* mask, float* out, int B, int64_t per_sample,
-                     int l1, int dtype, void* stream);
+                     int l1, int pred_dtype, int z_dtype, void* stream);
+/* out[b][i] = x[b][i] + a[b]*y[b][i], f32 out: predicted x0 = x_t - sigma*prediction
+ * (lbm_model.py:160,293-298). */
+int lbmk_axpy_rows(const void* x, const void* y, const float* a, float* out, int B,
+                   int64_t per_sample, int x_dtype, int y_dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * Layout / glue kernels.

@@ -56,7 +56,8 @@ SIGNATURES = {
     "lbmk_softmax_rows": (i32, [vp, vp, i64, i32, i64, i64, vp]),
     "lbmk_bridge_interp": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, i32, vp]),
     "lbmk_euler_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, i32, vp]),
-    "lbmk_latent_loss": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "lbmk_latent_loss": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+    "lbmk_axpy_rows": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "lbmk_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_nhwc_to_nchw": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_copy_channels": (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp]),

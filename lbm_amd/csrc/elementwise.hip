@@ -52,8 +52,8 @@ __global__ void euler_step_kernel(const T* __restrict__ x, const T* __restrict__
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void latent_loss_kernel(const T* __restrict__ pred,
+template <typename TP, typename T>
+__global__ __launch_bounds__(1024) void latent_loss_kernel(const TP* __restrict__ pred,
                                                            const T* __restrict__ zs,
                                                            const T* __restrict__ z,
                                                            const uint8_t* __restrict__ mask,
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(1024) void latent_loss_kernel(const T* __restrict__
   float acc = 0.f;
   for (int64_t i = threadIdx.x; i < per_sample; i += blockDim.x) {
     const float mk = mask ? (mask[base + i] ? 1.f : 0.f) : 1.f;
+    // the reference forms target = z_src - z in the latent dtype before the loss
     const float tgt = rnd<T>(ld(zs, base + i) - ld(z, base + i));
     const float d = (ld(pred, base + i) - tgt) * mk;
     acc += l1 ? fabsf(d) : d * d;
@@ -77,6 +78,19 @@ __global__ __launch_bounds__(1024) void latent_loss_kernel(const T* __restrict__
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
     out[b] = s / (float)per_sample;
   }
+}
+
+// out[b][i] = x[b][i] + a[b] * y[b][i]   (f32 out; predicted x0 = x_t - sigma * prediction)
+template <typename TX, typename TY>
+__global__ void axpy_rows_kernel(const TX* __restrict__ x, const TY* __restrict__ y,
+                                 const float* __restrict__ a, float* __restrict__ out,
+                                 int64_t per_sample) {
+  const int b = blockIdx.y;
+  const float av = a[b];
+  const int64_t base = (int64_t)b * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[base + i] = ld(x, base + i) + av * ld(y, base + i);
 }
 
 template <typename T>
@@ -242,17 +256,35 @@ extern "C" int lbmk_euler_step(const void* x, const void* pred, const void* eps,
 
 extern "C" int lbmk_latent_loss(const void* pred, const void* z_src, const void* z,
                                 const uint8_t* mask, float* out, int B, int64_t per_sample, int l1,
-                                int dtype, void* stream) {
+                                int pred_dtype, int z_dtype, void* stream) {
   LBMK_REQUIRE(pred && z_src && z && out, "latent_loss: null pointer");
-  LBMK_REQUIRE(B > 0 && per_sample > 0 && (dtype | 1) == 1, "latent_loss: sizes / dtype");
+  LBMK_REQUIRE(B > 0 && per_sample > 0 && (pred_dtype | 1) == 1 && (z_dtype | 1) == 1, "latent_loss: sizes / dtype");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == 0)
-    hipLaunchKernelGGL(latent_loss_kernel<bf16_t>, dim3(B), dim3(1024), 0, s, (const bf16_t*)pred,
-                       (const bf16_t*)z_src, (const bf16_t*)z, mask, out, per_sample, l1);
-  else
-    hipLaunchKernelGGL(latent_loss_kernel<float>, dim3(B), dim3(1024), 0, s, (const float*)pred,
-                       (const float*)z_src, (const float*)z, mask, out, per_sample, l1);
+#define LL(TP, TZ)                                                                                \
+  hipLaunchKernelGGL((latent_loss_kernel<TP, TZ>), dim3(B), dim3(1024), 0, s, (const TP*)pred,    \
+                     (const TZ*)z_src, (const TZ*)z, mask, out, per_sample, l1)
+  if (pred_dtype == 0 && z_dtype == 0) LL(bf16_t, bf16_t);
+  else if (pred_dtype == 0) LL(bf16_t, float);
+  else if (z_dtype == 0) LL(float, bf16_t);
+  else LL(float, float);
+#undef LL
   return lbmk_check_launch("latent_loss");
+}
+
+extern "C" int lbmk_axpy_rows(const void* x, const void* y, const float* a, float* out, int B,
+                              int64_t per_sample, int x_dtype, int y_dtype, void* stream) {
+  LBMK_REQUIRE(x && y && a && out && B > 0 && B <= 65535 && per_sample > 0, "axpy_rows: sizes");
+  LBMK_REQUIRE((x_dtype | 1) == 1 && (y_dtype | 1) == 1, "axpy_rows: dtype");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid1d(per_sample, 256, 1024), B);
+#define AX(TX, TY)                                                                              \
+  hipLaunchKernelGGL((axpy_rows_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x, (const TY*)y, a, out, per_sample)
+  if (x_dtype == 0 && y_dtype == 0) AX(bf16_t, bf16_t);
+  else if (x_dtype == 0) AX(bf16_t, float);
+  else if (y_dtype == 0) AX(float, bf16_t);
+  else AX(float, float);
+#undef AX
+  return lbmk_check_launch("axpy_rows");
 }
 
 extern "C" int lbmk_nchw_to_nhwc(const void* x, void* y, int B, int C, int H, int W, int Cp,

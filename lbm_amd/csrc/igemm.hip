@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
   const char* rdA = sA + (wm * WM + lr) * 128;
   const char* rdB = sB + (wn * WN + lr) * 128;
 
-  const int nkt = p.Kp >> 6;
+  const int nkt = (p.K + 63) >> 6;
   for (int kt = 0; kt < nkt; ++kt) {
     // ---- stage tile kt -----------------------------------------------------------------
     {
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         if (BN >= 32 || t < BN * 8) {
-          const bf16_t* src = w_ptr[i] ? w_ptr[i] + (kt << 6) : (const bf16_t*)igemm_zero_page;
+          const bf16_t* src = (w_ptr[i] && (kt << 6) + kk < p.K) ? w_ptr[i] + (kt << 6)
+                                                                   : (const bf16_t*)igemm_zero_page;
           glds16(src, sB + (wave * 8 + 32 * i) * 128);
         }
       }
@@ -257,7 +258,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
   LBMK_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "igemm: Cin=%d must be a multiple of 8", d.Cin);
   LBMK_REQUIRE(d.K == d.KH * d.KW * d.Cin, "igemm: K=%d != KH*KW*Cin", d.K);
-  LBMK_REQUIRE(d.Kp >= d.K && d.Kp % 64 == 0, "igemm: Kp=%d must be a multiple of 64 >= K", d.Kp);
+  LBMK_REQUIRE(d.Kp >= d.K && d.Kp % 8 == 0, "igemm: Kp=%d (row stride of w) must be a multiple of 8 >= K", d.Kp);
   LBMK_REQUIRE(d.a_cs % 8 == 0 && d.a_coff % 8 == 0 && d.a_coff >= 0 && d.a_coff + d.Cin <= d.a_cs,
                "igemm: channel window off=%d Cin=%d stride=%d", d.a_coff, d.Cin, d.a_cs);
   LBMK_REQUIRE(d.sa % 8 == 0 && d.sw % 8 == 0, "igemm: batch strides must keep 16-byte alignment");

@@ -1,0 +1,101 @@
+"""Parameter-holding layers whose forward runs on the HIP kernels.
+
+Each class subclasses the torch.nn layer diffusers uses, so parameter names, shapes and
+default initialisation are identical (checkpoints load with ``strict=True``); ``forward``
+never calls torch's implementation.  Activations are bf16 channels-last ``[B, H, W, C]``
+(equivalently ``[B, H*W, C]`` tokens).  Packed / converted weights are cached per layer
+and rebuilt when the parameter is modified in place, replaced, or moved.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _stamp(*tensors):
+    return tuple((t.data_ptr(), t._version, t.device, t.dtype) if t is not None else None for t in tensors)
+
+
+class _Cached:
+    """Small per-module cache keyed on the identity/version of the source parameters."""
+
+    def _cached(self, name, params, build):
+        key = _stamp(*params)
+        ent = self.__dict__.get("_pack_" + name)
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                ent = (key, build())
+            self.__dict__["_pack_" + name] = ent
+        return ent[1]
+
+
+class HipConv2d(nn.Conv2d, _Cached):
+    """3x3 / 1x1 convolution as implicit GEMM. ``asym_pad``: pad right/bottom only (VAE encoder
+    downsample: F.pad(x, (0, 1, 0, 1)) + stride-2 conv with padding 0)."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, asym_pad=False):
+        super().__init__(cin, cout, kernel_size, stride=stride, padding=0 if asym_pad else padding)
+        self.asym_pad = asym_pad
+
+    def packed(self) -> ops.PackedWeight:
+        return self._cached("w", (self.weight, self.bias), lambda: ops.pack_conv_weight(self.weight, self.bias))
+
+    def forward(self, x, *, up2=False, rowvec=None, residual=None, act=ops.ACT_NONE):
+        s = self.stride[0]
+        if self.asym_pad:
+            out_hw = (x.shape[1] // 2, x.shape[2] // 2)
+            return ops.conv2d(x, self.packed(), stride=s, pad=(0, 0), out_hw=out_hw, rowvec=rowvec,
+                              residual=residual, act=act)
+        return ops.conv2d(x, self.packed(), stride=s, pad=(self.padding[0], self.padding[1]), up2=up2,
+                          rowvec=rowvec, residual=residual, act=act)
+
+
+class HipLinear(nn.Linear, _Cached):
+    def packed(self) -> ops.PackedWeight:
+        return self._cached("w", (self.weight, self.bias), lambda: ops.pack_linear_weight(self.weight, self.bias))
+
+    def packed_geglu(self) -> ops.PackedWeight:
+        return self._cached("g", (self.weight, self.bias), lambda: ops.pack_geglu_weight(self.weight, self.bias))
+
+    def forward(self, x, *, residual=None, rowvec=None, rows_per_image=0, act=ops.ACT_NONE, geglu=False, out=None):
+        pw = self.packed_geglu() if geglu else self.packed()
+        return ops.linear(x, pw, residual=residual, rowvec=rowvec, rows_per_image=rows_per_image, act=act, out=out)
+
+
+class HipGroupNorm(nn.GroupNorm, _Cached):
+    def affine_f32(self):
+        return self._cached("a", (self.weight, self.bias),
+                            lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
+
+    def forward(self, x, silu: bool = False):
+        g, b = self.affine_f32()
+        return ops.groupnorm(x, g, b, self.num_groups, self.eps, silu)
+
+
+class HipLayerNorm(nn.LayerNorm, _Cached):
+    def affine_f32(self):
+        return self._cached("a", (self.weight, self.bias),
+                            lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
+
+    def forward(self, x):
+        g, b = self.affine_f32()
+        return ops.layernorm(x, g, b, self.eps)
+
+
+def fused_rows(module: _Cached, name: str, layers, bias: bool):
+    """Packs several Linear layers that share an input into one [sum N, K] weight."""
+    params = []
+    for l in layers:
+        params += [l.weight, l.bias]
+
+    def build():
+        w = torch.cat([l.weight.detach() for l in layers], 0)
+        b = None
+        if bias:
+            b = torch.cat([l.bias.detach() if l.bias is not None else torch.zeros(l.out_features, device=w.device, dtype=w.dtype)
+                           for l in layers], 0)
+        return ops.pack_linear_weight(w, b)
+
+    return module._cached(name, params, build)

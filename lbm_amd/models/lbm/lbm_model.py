@@ -1,0 +1,225 @@
+"""LBMModel with the reference's interface (src/lbm/models/lbm/lbm_model.py:17-408):
+``forward(batch) -> dict`` (bridge-matching training loss) and
+``sample(z, num_steps, conditioner_inputs, max_samples) -> Tensor`` (Euler bridge sampler).
+
+The bridge arithmetic runs in the HIP kernels (interpolant, Euler step + re-noise, latent
+loss); the Python control flow keeps the reference's order of random draws.  Keyword-only
+additions (default ``None`` = draw exactly like the reference):
+
+  * ``forward(..., bridge_eps=, timesteps=)`` — the noise of lbm_model.py:143 and the
+    timesteps of :134;
+  * ``sample(..., eps_list=)`` — the per-step noise of lbm_model.py:350.
+
+Not on the HIP path yet (raise NotImplementedError): the pixel loss (VAE-decode backward +
+LPIPS, lbm_model.py:172-175) and gradient propagation through the denoiser.
+"""
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..base.base_model import BaseModel
+from ..schedulers import FlowMatchEulerDiscreteScheduler
+from .lbm_config import LBMConfig
+
+
+class LBMModel(BaseModel):
+    @classmethod
+    def load_from_config(cls, config: LBMConfig):
+        return cls(config=config)
+
+    def __init__(self, config: LBMConfig, denoiser=None, training_noise_scheduler=None,
+                 sampling_noise_scheduler=None, vae=None, conditioner=None):
+        BaseModel.__init__(self, config)
+        self.vae = vae
+        self.denoiser = denoiser
+        self.conditioner = conditioner
+        self.sampling_noise_scheduler = sampling_noise_scheduler
+        self.training_noise_scheduler = training_noise_scheduler
+        self.timestep_sampling = config.timestep_sampling
+        self.latent_loss_type = config.latent_loss_type
+        self.latent_loss_weight = config.latent_loss_weight
+        self.pixel_loss_type = config.pixel_loss_type
+        self.pixel_loss_max_size = config.pixel_loss_max_size
+        self.pixel_loss_weight = config.pixel_loss_weight
+        self.logit_mean = config.logit_mean
+        self.logit_std = config.logit_std
+        self.prob = config.prob
+        self.selected_timesteps = config.selected_timesteps
+        self.source_key = config.source_key
+        self.target_key = config.target_key
+        self.mask_key = config.mask_key
+        self.bridge_noise_sigma = config.bridge_noise_sigma
+        self.num_iterations = nn.Parameter(torch.tensor(0, dtype=torch.float32), requires_grad=False)
+        self.lpips_loss = None
+
+    def on_fit_start(self, device: torch.device | None = None, *args, **kwargs):
+        super().on_fit_start(device=device, *args, **kwargs)
+        if self.vae is not None:
+            self.vae.on_fit_start(device=device, *args, **kwargs)
+        if self.conditioner is not None:
+            self.conditioner.on_fit_start(device=device, *args, **kwargs)
+
+    # ---- training loss ----------------------------------------------------------------------
+    def forward(self, batch: Dict[str, Any], step=0, batch_idx=0, *args, bridge_eps: Optional[torch.Tensor] = None,
+                timesteps: Optional[torch.Tensor] = None, **kwargs):
+        self.num_iterations += 1
+        if self.pixel_loss_weight > 0:
+            raise NotImplementedError("pixel loss (VAE decode backward / LPIPS) is not implemented on the HIP path")
+
+        if self.vae is not None:
+            z = self.vae.encode(batch[self.target_key])
+            downsampling_factor = self.vae.downsampling_factor
+        else:
+            z = batch[self.target_key]
+            downsampling_factor = 1
+
+        if self.mask_key in batch:
+            valid_mask = batch[self.mask_key].bool()[:, 0, :, :].unsqueeze(1)
+            valid_mask_for_latent = ~torch.max_pool2d((~valid_mask).float(), downsampling_factor, downsampling_factor).bool()
+            valid_mask_for_latent = valid_mask_for_latent.repeat((1, z.shape[1], 1, 1))
+        else:
+            valid_mask_for_latent = None          # all valid
+
+        source_image = batch[self.source_key]
+        z_source = self.vae.encode(source_image) if self.vae is not None else source_image
+
+        conditioning = self._get_conditioning(batch, *args, **kwargs)
+
+        timestep = timesteps if timesteps is not None else self._timestep_sampling(n_samples=z.shape[0], device=z.device)
+        timestep = timestep.to(z.device)
+
+        sched = self.training_noise_scheduler
+        sigmas = self._get_sigmas(sched, timestep, n_dim=4, device=z.device)
+        if bridge_eps is None:
+            bridge_eps = torch.randn_like(z)
+        t_cpu = timestep.detach().cpu()
+        copy_src = torch.tensor([bool(t.item() == sched.timesteps[0]) for t in t_cpu], device=z.device)
+        z, z_source = z.contiguous(), z_source.contiguous()
+        noisy_sample = ops.bridge_interp(z_source, z, bridge_eps.to(z.dtype).contiguous(), sigmas, self.bridge_noise_sigma,
+                                         copy_src=copy_src, out_dtype=torch.float32)
+
+        prediction = self.denoiser(sample=noisy_sample, timestep=timestep, conditioning=conditioning, *args, **kwargs)
+
+        neg_sig = -sigmas.reshape(-1)
+        denoised_sample = ops.axpy_rows(noisy_sample, prediction.contiguous(), neg_sig)
+
+        if self.latent_loss_weight > 0:
+            if self.latent_loss_type not in ("l2", "l1"):
+                raise NotImplementedError(f"Loss type {self.latent_loss_type} not implemented")
+            loss = ops.latent_loss(prediction.contiguous(), z_source, z, valid_mask_for_latent,
+                                   l1=self.latent_loss_type == "l1")
+            latent_recon_loss = loss.mean()
+        else:
+            loss = torch.zeros(z.shape[0], device=z.device)
+            latent_recon_loss = torch.zeros_like(loss)
+        pixel_loss = torch.zeros_like(latent_recon_loss)
+
+        return {"loss": loss.mean(), "latent_recon_loss": latent_recon_loss, "pixel_recon_loss": pixel_loss.mean(),
+                "predicted_hr": denoised_sample, "noisy_sample": noisy_sample}
+
+    def latent_loss(self, prediction, model_input, valid_latent_mask):
+        """Same signature as the reference (lbm_model.py:186-195): model_input is the target z_src - z."""
+        if self.latent_loss_type not in ("l2", "l1"):
+            raise NotImplementedError(f"Loss type {self.latent_loss_type} not implemented")
+        zeros = torch.zeros_like(model_input)
+        return ops.latent_loss(prediction.contiguous(), model_input.contiguous(), zeros, valid_latent_mask,
+                               l1=self.latent_loss_type == "l1")
+
+    def _get_conditioning(self, batch: Dict[str, Any], ucg_keys: List[str] = None, set_ucg_rate_zero=False, *args, **kwargs):
+        if self.conditioner is not None:
+            conditioning = self.conditioner(batch, ucg_keys=ucg_keys, set_ucg_rate_zero=set_ucg_rate_zero, vae=self.vae,
+                                            *args, **kwargs)
+            if conditioning and "cond" in conditioning:
+                crossattn = conditioning["cond"].get("crossattn")
+                if crossattn is not None and self.config.lighting_condition_weight != 1.0:
+                    conditioning["cond"]["crossattn"] = crossattn * self.config.lighting_condition_weight
+                concat = conditioning["cond"].get("concat")
+                if concat is not None and self.config.concat_condition_weight != 1.0:
+                    conditioning["cond"]["concat"] = concat * self.config.concat_condition_weight
+            return conditioning
+        return None
+
+    def _timestep_sampling(self, n_samples=1, device="cpu"):
+        """Host-side draws in the reference's order and from the same generators (lbm_model.py:277-291)."""
+        sched = self.training_noise_scheduler
+        if self.timestep_sampling == "uniform":
+            idx = torch.randint(0, sched.config.num_train_timesteps, (n_samples,), device="cpu")
+            return sched.timesteps[idx].to(device=device)
+        elif self.timestep_sampling == "log_normal":
+            u = torch.normal(mean=self.logit_mean, std=self.logit_std, size=(n_samples,), device="cpu")
+            u = torch.nn.functional.sigmoid(u)
+            indices = (u * sched.config.num_train_timesteps).long()
+            return sched.timesteps[indices].to(device=device)
+        elif self.timestep_sampling == "custom_timesteps":
+            idx = np.random.choice(len(self.selected_timesteps), n_samples, p=self.prob)
+            return torch.tensor(self.selected_timesteps, device=device, dtype=torch.long)[idx]
+
+    def _predicted_x_0(self, model_output, sample, sigmas=None):
+        return ops.axpy_rows(sample.contiguous(), model_output.contiguous(), -sigmas.reshape(-1))
+
+    def _get_sigmas(self, scheduler, timesteps, n_dim=4, dtype=torch.float32, device="cpu"):
+        """Exact-match lookup of each timestep in the schedule, on the host: the tables are a few
+        floats, so no device round trip per sample (the reference does B ``.item()`` syncs, :304)."""
+        sched_t = scheduler.timesteps.detach().cpu()
+        sig = scheduler.sigmas.detach().cpu().to(dtype)
+        t_cpu = timesteps.detach().cpu()
+        idx = [(sched_t == t).nonzero().item() for t in t_cpu]
+        sigma = sig[idx].flatten().to(device)
+        while len(sigma.shape) < n_dim:
+            sigma = sigma.unsqueeze(-1)
+        return sigma
+
+    # ---- sampling ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, z: torch.Tensor, num_steps: int = 20, conditioner_inputs: Optional[Dict[str, Any]] = None,
+               max_samples: Optional[int] = None, verbose: bool = False, *, eps_list: Optional[List[torch.Tensor]] = None):
+        sched = self.sampling_noise_scheduler
+        sched.set_timesteps(sigmas=np.linspace(1, 1 / num_steps, num_steps))
+        sample = z
+        conditioning = self._get_conditioning(conditioner_inputs, set_ucg_rate_zero=True, device=z.device)
+        if max_samples is not None:
+            sample = sample[:max_samples]
+        if conditioning:
+            conditioning["cond"] = {k: v[:max_samples] for k, v in conditioning["cond"].items()}
+        sample = sample.contiguous()
+        fused = isinstance(sched, FlowMatchEulerDiscreteScheduler)
+        n = len(sched.timesteps)
+        for i, t in enumerate(sched.timesteps):
+            denoiser_input = sched.scale_model_input(sample, t) if hasattr(sched, "scale_model_input") else sample
+            pred = self.denoiser(sample=denoiser_input, timestep=t.to(z.device).repeat(denoiser_input.shape[0]),
+                                 conditioning=conditioning)
+            last = i == n - 1
+            eps = None
+            if not last:
+                eps = eps_list[i].to(sample) if eps_list is not None else torch.randn_like(sample)
+            if fused:
+                # Euler step and bridge re-noise in one kernel (f32 math, cast to the latent dtype)
+                sample = sched.step(pred, t, sample, return_dict=False, eps=eps,
+                                    bridge_noise_sigma=self.bridge_noise_sigma)[0]
+            else:
+                sample = sched.step(pred, t, sample, return_dict=False)[0]
+                if not last:
+                    s_next = float(sched.sigmas[i + 1])
+                    sample = ops.euler_step(sample.contiguous(), sample.contiguous(), s_next, s_next, eps=eps,
+                                            bridge_sigma=self.bridge_noise_sigma)
+            sample = sample.to(z.dtype)
+        return self.vae.decode(sample) if self.vae is not None else sample
+
+    def log_samples(self, batch: Dict[str, Any], input_shape: Optional[Tuple[int, int, int]] = None,
+                    max_samples: Optional[int] = None, num_steps: Union[int, List[int]] = 20):
+        if isinstance(num_steps, int):
+            num_steps = [num_steps]
+        logs = {}
+        N = max_samples if max_samples is not None else len(batch[self.source_key])
+        batch = {k: v[:N] for k, v in batch.items()}
+        if input_shape is None and self.vae is None:
+            raise ValueError("input_shape must be passed when no VAE is used in the model")
+        for num_step in num_steps:
+            source_image = torch.nn.functional.interpolate(batch[self.source_key], size=batch[self.target_key].shape[2:],
+                                                           mode="bilinear", align_corners=False).to(dtype=self.dtype)
+            z = self.vae.encode(source_image) if self.vae is not None else source_image
+            logs[f"samples_{num_step}_steps"] = self.sample(z, num_steps=num_step, conditioner_inputs=batch, max_samples=N)
+        return logs

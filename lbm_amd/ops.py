@@ -58,20 +58,28 @@ class PackedWeight:
     KH: int
     KW: int
     geglu: bool = False
+    alg_nk: int = 0                 # un-padded N*K of the layer (algorithmic MACs per output row)
 
 
 def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
-    """[Cout, Cin, KH, KW] -> bf16 [Cout, Kp] with k = (kh*KW + kw)*Cin_p + c."""
+    """[Cout, Cin, KH, KW] -> bf16 [Cout_p, Kp] with k = (kh*KW + kw)*Cin_p + c.
+    Both channel counts are padded to multiples of 8 with zeros, so every channels-last
+    tensor in the pipeline has 16-byte pixel rows (a 3- or 4-channel output carries zero
+    channels up to 8)."""
     N, Cin, KH, KW = weight.shape
     cin_p = ceil_to(Cin, 8)
+    n_p = ceil_to(N, 8)
     K = KH * KW * cin_p
     Kp = ceil_to(K, 64)
     w = torch.zeros(N, KH * KW, cin_p, dtype=bf16, device=weight.device)
     w[:, :, :Cin] = weight.detach().permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(bf16)
-    packed = torch.zeros(N, Kp, dtype=bf16, device=weight.device)
-    packed[:, :K] = w.reshape(N, K)
-    b = None if bias is None else bias.detach().float().contiguous()
-    return PackedWeight(packed.contiguous(), b, N, K, Kp, cin_p, KH, KW)
+    packed = torch.zeros(n_p, Kp, dtype=bf16, device=weight.device)
+    packed[:N, :K] = w.reshape(N, K)
+    b = None
+    if bias is not None:
+        b = torch.zeros(n_p, dtype=torch.float32, device=weight.device)
+        b[:N] = bias.detach().float()
+    return PackedWeight(packed.contiguous(), b, n_p, K, Kp, cin_p, KH, KW, alg_nk=N * KH * KW * Cin)
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
@@ -82,7 +90,7 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pa
     packed = torch.zeros(N, Kp, dtype=bf16, device=weight.device)
     packed[:, :K] = weight.detach().to(bf16)
     b = None if bias is None else bias.detach().float().contiguous()
-    return PackedWeight(packed, b, N, k8, Kp, k8, 1, 1)
+    return PackedWeight(packed, b, N, k8, Kp, k8, 1, 1, alg_nk=N * K)
 
 
 def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
@@ -103,8 +111,35 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pac
 # --------------------------------------------------------------------------------------
 # implicit GEMM
 # --------------------------------------------------------------------------------------
-def _igemm(desc: IgemmDesc):
+_profile = None   # when a dict: per-launch HIP-event timing of the implicit-GEMM kernel (bench.py)
+
+
+def igemm_profile_begin():
+    global _profile
+    _profile = {"events": [], "flops": 0.0}
+
+
+def igemm_profile_end() -> dict:
+    """Sum of the event-bracketed launch durations (ms), algorithmic FLOPs and launch count."""
+    global _profile
+    p, _profile = _profile, None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in p["events"])
+    return {"ms": ms, "flops": p["flops"], "launches": len(p["events"])}
+
+
+def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None):
+    if _profile is None:
+        check(lib.lbmk_igemm(C.byref(desc), _stream()), "lbmk_igemm")
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()          # torch's current stream is the stream the kernel is launched on
     check(lib.lbmk_igemm(C.byref(desc), _stream()), "lbmk_igemm")
+    b.record()
+    _profile["events"].append((a, b))
+    if alg_flops is None:
+        alg_flops = 2.0 * desc.M * desc.N * desc.K * desc.batch
+    _profile["flops"] += alg_flops
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up2: bool = False,
@@ -136,16 +171,18 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
     d.up2 = 1 if up2 else 0
     d.ldo = n_out
     d.ldr = residual.shape[-1] if residual is not None else 0
-    d.rowvec_ld = rowvec.shape[-1] if rowvec is not None else 0
+    d.rowvec_ld = rowvec.stride(0) if rowvec is not None else 0
     if residual is not None:
         assert residual.dtype == bf16 and residual.is_contiguous() and residual.numel() == d.M * d.ldr
     if rowvec is not None:
-        assert rowvec.dtype == bf16 and rowvec.is_contiguous() and rowvec.shape[0] == B
+        # [B, N] rows, possibly a column window of a wider matrix
+        assert rowvec.dtype == bf16 and rowvec.dim() == 2 and rowvec.stride(1) == 1
+        assert rowvec.shape == (B, pw.N)
     d.act = ACT_GEGLU if pw.geglu else act
     d.out_f32, d.bias_per_m, d.alpha = 0, 0, 1.0
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
-    _igemm(d)
+    _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
     return out
 
 
@@ -177,7 +214,8 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
         # rows of one image are consecutive: model them as a rows_per_image x 1 "image"
         assert rows_per_image > 0 and M % rows_per_image == 0
         d.IH, d.IW, d.OH, d.OW = rows_per_image, 1, rows_per_image, 1
-        d.rowvec_ld = rowvec.shape[-1]
+        assert rowvec.dtype == bf16 and rowvec.dim() == 2 and rowvec.stride(1) == 1
+        d.rowvec_ld = rowvec.stride(0)
     else:
         d.IH = d.IW = d.OH = d.OW = 1
         d.rowvec_ld = 0
@@ -190,7 +228,7 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
     d.bias_per_m, d.alpha = 0, 1.0
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
-    _igemm(d)
+    _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
     return out
 
 
@@ -204,8 +242,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     Z = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
     M, K = a.shape[-2], a.shape[-1]
     N = b.shape[-2]
-    assert b.shape[-1] == K and K % 64 == 0
-    assert b.stride(-2) == K, "b rows must be densely packed (row stride = K)"
+    assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0
     shape = (Z, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
     out = torch.empty(*shape, dtype=out_dtype, device=a.device)
     d = IgemmDesc()
@@ -215,7 +252,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     d.bias_per_m = 1 if bias_m is not None else 0
     d.rowvec = None
     d.residual = _ptr(residual)
-    d.M, d.N, d.K, d.Kp = M, N, K, K
+    d.M, d.N, d.K, d.Kp = M, N, K, b.stride(-2)
     d.Cin, d.a_cs, d.a_coff = K, a.stride(-2), 0
     d.IH = d.IW = d.OH = d.OW = 1
     d.KH = d.KW = d.stride = 1
@@ -335,15 +372,28 @@ def euler_step(x, pred, s: float, s_next: float, eps=None, bridge_sigma: float =
 
 
 def latent_loss(pred, z_src, z, mask=None, l1: bool = False):
+    """per-sample mean of ((pred - (z_src - z)) * mask)^2 or |.|; pred may be f32 while z is bf16."""
     _need_gpu(pred, z_src, z, mask)
-    assert pred.shape == z.shape == z_src.shape and pred.dtype == z.dtype == z_src.dtype
+    assert pred.shape == z.shape == z_src.shape and z.dtype == z_src.dtype
     assert pred.is_contiguous() and z.is_contiguous() and z_src.is_contiguous()
     B = z.shape[0]
     if mask is not None:
         mask = mask.expand_as(z).to(torch.uint8).contiguous()
     out = torch.empty(B, dtype=torch.float32, device=z.device)
     check(lib.lbmk_latent_loss(pred.data_ptr(), z_src.data_ptr(), z.data_ptr(), _ptr(mask), out.data_ptr(), B,
-                               z[0].numel(), 1 if l1 else 0, _dt(z), _stream()), "lbmk_latent_loss")
+                               z[0].numel(), 1 if l1 else 0, _dt(pred), _dt(z), _stream()), "lbmk_latent_loss")
+    return out
+
+
+def axpy_rows(x, y, a):
+    """out[b] = x[b] + a[b] * y[b] in f32 (a: f32 [B])."""
+    _need_gpu(x, y, a)
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous()
+    B = x.shape[0]
+    a = a.reshape(B).float().contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.lbmk_axpy_rows(x.data_ptr(), y.data_ptr(), a.data_ptr(), out.data_ptr(), B, x[0].numel(),
+                             _dt(x), _dt(y), _stream()), "lbmk_axpy_rows")
     return out
 
 

@@ -31,9 +31,25 @@ import torch.nn.functional as F
 
 SD = Dict[str, torch.Tensor]
 
+# Arithmetic dtype of the restatement.  fp32 is the oracle of record; bfloat16 reproduces how the
+# reference actually executes (every builder casts the model with ``.to(torch.bfloat16)``, e.g.
+# src/lbm/inference/utils.py:164,220), which tests use to put the bf16 error of the HIP path in context.
+_COMPUTE = [torch.float32]
+
+
+class compute_dtype:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        _COMPUTE.append(self.dtype)
+
+    def __exit__(self, *a):
+        _COMPUTE.pop()
+
 
 def _p(sd: SD, key: str) -> torch.Tensor:
-    return sd[key].float()
+    return sd[key].to(_COMPUTE[-1])
 
 
 def _has(sd: SD, key: str) -> bool:
@@ -48,8 +64,8 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int = 320) -> torch.Tensor:
     cos half first (src/lbm/inference/utils.py:116-117 sets flip_sin_to_cos / freq_shift)."""
     half = dim // 2
     exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
-    emb = timesteps.float()[:, None] * torch.exp(exponent)[None, :]
-    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    emb = timesteps.float()[:, None] * torch.exp(exponent).to(timesteps.device)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1).to(_COMPUTE[-1])
 
 
 def conv(sd: SD, prefix: str, x, stride=1, padding=1):

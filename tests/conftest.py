@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow_oracle: runs the full-size fp32 oracle on the host cores (tens of seconds)")
 
 
 @pytest.fixture(scope="session")

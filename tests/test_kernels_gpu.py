@@ -160,7 +160,9 @@ def test_conv_thin_channels(ops, cuda, gen, cin, cout):
     pw = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
     y = ops.conv2d(x, pw)
     ref = F.conv2d(x_nchw.float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
-    assert rel_l2(y, ref) < 4e-3
+    assert y.shape[-1] == (cout + 7) // 8 * 8          # output channels are padded to 8 with zeros
+    assert float(y[..., cout:].float().abs().sum()) == 0.0
+    assert rel_l2(y[..., :cout], ref) < 4e-3
     back = ops.nhwc_to_nchw(y, cout, out_dtype=torch.float32)
     assert rel_l2(back, ref.permute(0, 3, 1, 2)) < 4e-3
 
@@ -324,7 +326,7 @@ def test_errors_are_loud(ops, cuda, gen):
     x = randbf(gen, 10, 24).to(cuda)
     w = randbf(gen, 16, 24)
     pw = ops.pack_linear_weight(w.to(cuda), None)
-    pw.Kp = 24  # corrupt: not a multiple of 64
+    pw.Kp = 20  # corrupt: row stride smaller than K and not a multiple of 8
     with pytest.raises(LbmkError):
         ops.linear(x, pw)
     with pytest.raises(RuntimeError):
