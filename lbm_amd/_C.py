@@ -6,6 +6,12 @@ There is no fallback: importing this module without the shared library raises.
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64.so.  It must be the first HIP runtime in the process:
+# liblbmk.so then binds to it (same SONAME) and shares torch's device context and streams.
+# Loading liblbmk.so first would pull in /opt/rocm's copy as a second runtime, whose launches fail
+# with "no ROCm-capable device is detected" once torch has initialised its own.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblbmk.so")
 

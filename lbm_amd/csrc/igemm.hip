@@ -17,17 +17,19 @@
 
 __device__ __attribute__((aligned(16))) uint32_t igemm_zero_page[8];
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbmk_igemm_desc p) {
+  constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
+  constexpr int NT = 64 * NW;
+  constexpr int RPP = NT / 8;                   // tile rows staged by one LDS-DMA instruction of the block
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int AI = BM / 32;                 // LDS-DMA loads per thread for the A tile
-  constexpr int BI = (BN >= 32) ? BN / 32 : 1;
-  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile");
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128];
-  char* sA = smem;
-  char* sB = smem + BM * 128;
+  constexpr int AI = BM / RPP;                  // LDS-DMA loads per thread for the A tile
+  constexpr int BI = (BN >= RPP) ? BN / RPP : 1;
+  constexpr int STAGE = (BM + BN) * 128;        // bytes of one K-tile (64 deep) of both operands
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % RPP == 0, "tile shape");
+  // all LDS in ONE array: a second __shared__ object makes hipcc drain vmcnt before every ds_read
+  __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * STAGE];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -53,16 +55,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
 
   // ---- per-thread staging coordinates -------------------------------------------------
   const int slot = t & 7;          // 16-byte slot inside a 128-byte LDS row
-  const int rsub = t >> 3;         // row inside a 32-row group
+  const int rsub = t >> 3;         // row inside an RPP-row group
   const int kk = (slot ^ ((rsub >> 1) & 7)) * 8;   // swizzled k offset inside the 64-wide tile
   const int ohw = p.OH * p.OW;
   const int IHe = p.up2 ? 2 * p.IH : p.IH;
   const int IWe = p.up2 ? 2 * p.IW : p.IW;
+  const bool b_loader = (BN >= RPP) || (t < BN * 8);
 
   int a_by[AI], a_bx[AI], a_boff[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int m = m0 + rsub + 32 * i;
+    const int m = m0 + rsub + RPP * i;
     if (m < p.M) {
       const int b = m / ohw, rem = m - b * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
   const bf16_t* w_ptr[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int n = n0 + rsub + 32 * i;
-    w_ptr[i] = (n < p.N && (BN >= 32 || t < BN * 8)) ? W + (int64_t)n * p.Kp + kk : nullptr;
+    const int n = n0 + rsub + RPP * i;
+    w_ptr[i] = (n < p.N && b_loader) ? W + (int64_t)n * p.Kp + kk : nullptr;
   }
 
   // running (tap, channel) of this thread's 8-element chunk
@@ -95,56 +98,78 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
 
   const int lr = lane & 15, lq = lane >> 4;
   const int rd_swz = lr >> 1;   // (row >> 1) & 7 for every fragment row of this lane
-  const char* rdA = sA + (wm * WM + lr) * 128;
-  const char* rdB = sB + (wn * WN + lr) * 128;
+  const int rdA = (wm * WM + lr) * 128;
+  const int rdB = BM * 128 + (wn * WN + lr) * 128;
 
-  const int nkt = (p.K + 63) >> 6;
-  for (int kt = 0; kt < nkt; ++kt) {
-    // ---- stage tile kt -----------------------------------------------------------------
-    {
-      int kh = 0, kw = 0;
-      if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-      const bool tap_ok = tap < ntaps;
+  // issue the LDS-DMA loads of K-tile kt into stage buffer `buf`, then advance (tap, ch)
+  auto stage = [&](int kt, char* buf) {
+    int kh = 0, kw = 0;
+    if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
+    const bool tap_ok = tap < ntaps;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        int iy = a_by[i] + kh, ix = a_bx[i] + kw;
-        const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
-        if (p.up2) { iy >>= 1; ix >>= 1; }
-        const bf16_t* src = ok
-            ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
-            : (const bf16_t*)igemm_zero_page;
-        glds16(src, sA + (wave * 8 + 32 * i) * 128);
-      }
-#pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        if (BN >= 32 || t < BN * 8) {
-          const bf16_t* src = (w_ptr[i] && (kt << 6) + kk < p.K) ? w_ptr[i] + (kt << 6)
-                                                                   : (const bf16_t*)igemm_zero_page;
-          glds16(src, sB + (wave * 8 + 32 * i) * 128);
-        }
-      }
-      ch += 64;
-      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    for (int i = 0; i < AI; ++i) {
+      int iy = a_by[i] + kh, ix = a_bx[i] + kw;
+      const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
+      if (p.up2) { iy >>= 1; ix >>= 1; }
+      const bf16_t* src = ok
+          ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
+          : (const bf16_t*)igemm_zero_page;
+      glds16(src, buf + (wave * 8 + RPP * i) * 128);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if (b_loader) {
+        const bf16_t* src = (w_ptr[i] && (kt << 6) + kk < p.K) ? w_ptr[i] + (kt << 6)
+                                                                 : (const bf16_t*)igemm_zero_page;
+        glds16(src, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
+      }
+    }
+    ch += 64;
+    while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+  };
 
-    // ---- MFMA over the 64-deep tile ----------------------------------------------------
+  // MFMA over one staged 64-deep tile
+  auto compute = [&](const char* buf) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int off = ((ks * 4 + lq) ^ rd_swz) << 4;
       bf16x8 fa[MI], fb[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(rdA + i * 16 * 128 + off);
+      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(buf + rdB + j * 16 * 128 + off);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(rdB + j * 16 * 128 + off);
+      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(buf + rdA + i * 16 * 128 + off);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
+  };
+
+  const int nkt = (p.K + 63) >> 6;
+  if constexpr (DBUF) {
+    // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
+    // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
+    // wave has finished when it passed the barrier that ended iteration kt-1.
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+      compute(smem + (kt & 1) * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nkt; ++kt) {
+      stage(kt, smem);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -233,14 +258,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const lbmk_igemm_desc p) {
 // ---- host side ------------------------------------------------------------------------------
 namespace {
 struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}};
+const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}, {256, 256}, {256, 128}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int BM, int BN, int WMs, int WNs>
+template <int BM, int BN, int WMs, int WNs, bool DBUF>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs>), grid, dim3(256), 0, s, d);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
 
@@ -293,11 +318,13 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
-    case 0: launch<128, 128, 2, 2>(d, s); break;
-    case 1: launch<128, 64, 2, 2>(d, s); break;
-    case 2: launch<256, 16, 4, 1>(d, s); break;
-    case 3: launch<64, 64, 2, 2>(d, s); break;
-    case 4: launch<256, 64, 4, 1>(d, s); break;
+    case 0: launch<128, 128, 2, 2, false>(d, s); break;
+    case 1: launch<128, 64, 2, 2, false>(d, s); break;
+    case 2: launch<256, 16, 4, 1, false>(d, s); break;
+    case 3: launch<64, 64, 2, 2, false>(d, s); break;
+    case 4: launch<256, 64, 4, 1, false>(d, s); break;
+    case 5: launch<256, 256, 2, 4, true>(d, s); break;
+    case 6: launch<256, 128, 4, 2, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
