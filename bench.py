@@ -68,9 +68,10 @@ def cpu_baseline(model, threads):
     vsd = {k: v.detach().float().cpu() for k, v in model.vae.vae_model.state_dict().items()}
     from lbm_amd.inference.utils import sdxl_style_unet_kwargs
     cfg = sdxl_style_unet_kwargs()
+    n = 4
     g = torch.Generator().manual_seed(1234)
-    x = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
-    eps = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(4321))
+    x = torch.rand(n, 3, 512, 512, generator=g) * 2 - 1
+    eps = torch.randn(n, 4, 64, 64, generator=torch.Generator().manual_seed(4321))
     t0 = time.perf_counter()
     with torch.no_grad():
         z = dr.posterior_sample(dr.vae_encode_moments(vsd, x), eps) * 0.13025
@@ -78,9 +79,10 @@ def cpu_baseline(model, threads):
         img = dr.vae_decode(vsd, lat / 0.13025)
     dt = time.perf_counter() - t0
     assert torch.isfinite(img).all()
-    return {"value": 1.0 / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 image 512x512, 1 NFE, fp32 torch CPU oracle, {dt:.1f} s "
-                      f"(5.33 TFLOP/image; the 1024x1024 workload is 23.25 TFLOP/image, i.e. ~{dt * 23.25 / 5.33:.0f} s/image extrapolated by FLOPs)"}
+    return {"value": round(n / dt, 4), "unit": "images/s (512x512)", "cores": threads, "kind": "port",
+            "sample": f"{n} images 512x512, 1 NFE, fp32 torch CPU oracle, {dt:.1f} s "
+                      f"(5.33 TFLOP/image; the 1024x1024 workload is 23.25 TFLOP/image, i.e. "
+                      f"~{n / dt * 5.33 / 23.25:.3f} images/s extrapolated by FLOPs)"}
 
 
 def main():
@@ -95,17 +97,13 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from lbm_amd import dist as D
+    rank, local_rank, world = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+    dist = D.init("nccl", device)       # nccl = RCCL; used for the timing barrier / max only
 
     from lbm_amd import ops
     model = build_model(device, args.res)
@@ -117,22 +115,17 @@ def main():
     for _ in range(args.warmup):
         out = one_step(model, images, enc_eps, args.nfe)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    D.barrier(dist)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step(model, images, enc_eps, args.nfe)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    D.barrier(dist)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert out.shape == (args.batch, 3, args.res, args.res) and bool(torch.isfinite(out.float()).all())
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = D.max_over_ranks(elapsed, dist, device)
 
     roofline, cpu = None, None
     if rank == 0 and not args.no_roofline:
