@@ -312,6 +312,10 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       else if (d.N % 64 == 0) tile = (d.M >= 65536) ? 4 : 1;
       else tile = 0;
       if (tile == 0 && blocks128 < 256 && d.act != LBMK_ACT_GEGLU) tile = 3;
+      // 256x256 double-buffered tile: half the L2->LDS bytes per FLOP; pays once the grid still
+      // fills the chip a few times over and K is deep enough to amortise its longer prologue
+      const long blocks256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
+      if (tile == 0 && d.N >= 512 && d.K >= 2048 && blocks256 >= 768) tile = 5;
     }
   }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);

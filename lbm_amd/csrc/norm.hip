@@ -57,15 +57,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     const int r0 = slab * rows_per_slab;
     const int r1 = min(r0 + rows_per_slab, HW);
     const bf16_t* base = x + ((int64_t)b * HW) * C + seg * cseg + chunk * 8;
-    for (int r = r0 + rl; r < r1; r += rpp) {
-      const u16x8 v = *(const u16x8*)(base + (int64_t)r * C);
+    auto accum = [&](const u16x8& v) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f = bf2f(v.v[e]);
         s[e] += f;
         ss[e] += f * f;
       }
+    };
+    int r = r0 + rl;
+    // four independent 16-byte loads in flight per lane
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {
+      const u16x8 v0 = *(const u16x8*)(base + (int64_t)r * C);
+      const u16x8 v1 = *(const u16x8*)(base + (int64_t)(r + rpp) * C);
+      const u16x8 v2 = *(const u16x8*)(base + (int64_t)(r + 2 * rpp) * C);
+      const u16x8 v3 = *(const u16x8*)(base + (int64_t)(r + 3 * rpp) * C);
+      accum(v0); accum(v1); accum(v2); accum(v3);
     }
+    for (; r < r1; r += rpp) accum(*(const u16x8*)(base + (int64_t)r * C));
     // fold the 8 channels into their groups (consecutive channels share a group)
     int gprev = (chunk * 8) / cpg;
     float as = 0.f, ass = 0.f;
@@ -134,8 +143,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int r0 = slab * rows_per_slab;
   const int r1 = min(r0 + rows_per_slab, HW);
   const int64_t base = ((int64_t)b * HW) * C + c0;
-  for (int r = r0 + rl; r < r1; r += rpp) {
-    const u16x8 v = *(const u16x8*)(x + base + (int64_t)r * C);
+  auto apply = [&](const u16x8& v, int64_t row) {
     u16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -143,8 +151,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
       if (SILU) f = silu_f(f);
       o.v[e] = f2bf(f);
     }
-    *(u16x8*)(y + base + (int64_t)r * C) = o;
+    *(u16x8*)(y + base + row * C) = o;
+  };
+  int r = r0 + rl;
+  for (; r + 3 * rpp < r1; r += 4 * rpp) {      // four independent 16-byte loads in flight per lane
+    const u16x8 v0 = *(const u16x8*)(x + base + (int64_t)r * C);
+    const u16x8 v1 = *(const u16x8*)(x + base + (int64_t)(r + rpp) * C);
+    const u16x8 v2 = *(const u16x8*)(x + base + (int64_t)(r + 2 * rpp) * C);
+    const u16x8 v3 = *(const u16x8*)(x + base + (int64_t)(r + 3 * rpp) * C);
+    apply(v0, r); apply(v1, r + rpp); apply(v2, r + 2 * rpp); apply(v3, r + 3 * rpp);
   }
+  for (; r < r1; r += rpp) apply(*(const u16x8*)(x + base + (int64_t)r * C), r);
 }
 
 // one wave per row; NC = 8-channel chunks per lane
@@ -190,11 +207,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     const int c = lane + 64 * i;
     if (c < nchunks) {
       u16x8 o;
+      f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (gamma) { g0 = *(const f32x4*)(gamma + c * 8); g1 = *(const f32x4*)(gamma + c * 8 + 4); }
+      if (beta) { b0 = *(const f32x4*)(beta + c * 8); b1 = *(const f32x4*)(beta + c * 8 + 4); }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ci = c * 8 + e;
-        const float ga = gamma ? gamma[ci] : 1.f, be = beta ? beta[ci] : 0.f;
-        o.v[e] = f2bf((v[i][e] - mean) * rstd * ga + be);
+      for (int e = 0; e < 4; ++e) {
+        o.v[e] = f2bf((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+        o.v[e + 4] = f2bf((v[i][e + 4] - mean) * rstd * g1[e] + b1[e]);
       }
       *(u16x8*)(yr + c * 8) = o;
     }
@@ -240,7 +259,8 @@ extern "C" int lbmk_layernorm(const void* x, void* y, const float* gamma, const 
                               int rows, int C, float eps, void* stream) {
   LBMK_REQUIRE(x && y, "layernorm: null pointer");
   LBMK_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, "layernorm: rows=%d C=%d (C %% 8 == 0, <= 2048)", rows, C);
-  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16), "layernorm: misaligned");
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16) && lbmk_aligned(gamma, 16) && lbmk_aligned(beta, 16),
+               "layernorm: x / y / gamma / beta must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4);
   const int nc = (C / 8 + 63) / 64;
