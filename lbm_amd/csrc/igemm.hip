@@ -258,7 +258,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
 // ---- host side ------------------------------------------------------------------------------
 namespace {
 struct TileCfg { int bm, bn; };
-const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}, {256, 256}, {256, 128}};
+const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}, {256, 256}, {256, 128},
+                          {256, 256},    // 7: 256x256 with 16 waves (64x64 per wave)
+                          {512, 128},    // 8: 16 waves, for N = 128 layers
+                          {256, 128}};   // 9: 16 waves (64x32 per wave)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int BM, int BN, int WMs, int WNs, bool DBUF>
@@ -312,10 +315,14 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       else if (d.N % 64 == 0) tile = (d.M >= 65536) ? 4 : 1;
       else tile = 0;
       if (tile == 0 && blocks128 < 256 && d.act != LBMK_ACT_GEGLU) tile = 3;
-      // 256x256 double-buffered tile: half the L2->LDS bytes per FLOP; pays once the grid still
-      // fills the chip a few times over and K is deep enough to amortise its longer prologue
+      // 16-wave double-buffered tiles (one workgroup per CU, 4 waves per SIMD): 256x256 halves the
+      // L2->LDS bytes per FLOP of the 128x128 tile, 512x128 does the same for narrow outputs.
+      // They pay once the grid still fills the 256 CUs a few times over (measured crossover).
       const long blocks256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
-      if (tile == 0 && d.N >= 512 && d.K >= 2048 && blocks256 >= 768) tile = 5;
+      const long blocks512 = (long)((d.M + 511) / 512) * ((d.N + 127) / 128) * d.batch;
+      const bool fits256 = ((d.N + 255) / 256) * 256 * 4 <= d.N * 5;   // <= 25 % padded columns
+      if (d.N >= 256 && fits256 && blocks256 >= 600) tile = 7;
+      else if (d.N >= 64 && blocks512 >= 600) tile = 8;
     }
   }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
@@ -329,6 +336,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 4: launch<256, 64, 4, 1, false>(d, s); break;
     case 5: launch<256, 256, 2, 4, true>(d, s); break;
     case 6: launch<256, 128, 4, 2, true>(d, s); break;
+    case 7: launch<256, 256, 4, 4, true>(d, s); break;
+    case 8: launch<512, 128, 8, 2, true>(d, s); break;
+    case 9: launch<256, 128, 4, 4, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }

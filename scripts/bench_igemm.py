@@ -25,8 +25,9 @@ def timeit(fn, iters=5):
 
 tiles = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 5, 6]
 cases = []
-for (B, H, cin, cout) in [(4, 1024, 128, 128), (8, 512, 256, 256), (16, 256, 512, 512), (16, 128, 512, 512),
-                          (16, 64, 640, 640), (16, 32, 1280, 1280), (16, 32, 2560, 1280)]:
+for (B, H, cin, cout) in [(4, 1024, 128, 128), (4, 1024, 256, 128), (8, 512, 256, 256), (16, 256, 512, 512),
+                          (16, 128, 512, 512), (16, 128, 320, 320), (16, 128, 960, 320), (16, 64, 640, 640),
+                          (16, 32, 1280, 1280), (16, 32, 2560, 1280)]:
     x = rnd(B, H, H, cin)
     w = rnd(cout, cin, 3, 3) * (9 * cin) ** -0.5
     pw = ops.pack_conv_weight(w, torch.zeros(cout, device=dev))
