@@ -159,6 +159,165 @@ __global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
   }
 }
 
+// Same algorithm for any head_dim that is a multiple of 8 (the SD1.5-style UNet has 40 / 80 / 160):
+// the K image is [key][ceil16(D)] with the pad chunk read from the zero page, O^T has ceil(D/32) tiles.
+template <int DH>
+__global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+    bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
+    int64_t sk, int64_t svt, int64_t so, float scale_log2e) {
+  constexpr int KS = (DH + 15) / 16;     // 16-deep MFMA steps over the head dim
+  constexpr int DT = (DH + 31) / 32;     // 32-row tiles of O^T
+  constexpr int KROW = KS * 32;          // bytes per key row of the K image
+  constexpr int KCHUNKS = KB * KS * 2;   // 16-byte chunks of one K tile
+  constexpr int KI = (KCHUNKS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[KB * KROW + DT * 32 * 128];
+  char* sK = smem;
+  char* sV = smem + KB * KROW;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * 32;
+
+  Q += b * sq + head * DH;
+  K += b * sk + head * DH;
+  Vt += b * svt + (int64_t)head * DH * ldvt;
+  O += b * so + head * DH;
+
+  bf16x8 qf[KS];
+  {
+    const int qr = min(q0 + r, Nq - 1);
+    const bf16_t* qp = Q + (int64_t)qr * ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (16 * ks + 8 * h + 8 <= DH) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)0.f;
+      }
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int slot = t & 7, rsub = t >> 3;
+  const int cs = slot ^ ((rsub >> 1) & 7);
+  const int rswz = (r >> 1) & 7;
+
+  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int idx = i * 256 + t;
+      if (idx < KCHUNKS) {                       // whole waves are in or out (KCHUNKS % 64 == 0)
+        const int row = idx / (KS * 2), c = idx - row * (KS * 2);
+        const int key = kv0 + row;
+        const bf16_t* src = (key < Nk && c * 8 < DH) ? K + (int64_t)key * ldk + c * 8
+                                                     : (const bf16_t*)attn_zero_page;
+        glds16(src, sK + (i * 256 + wave * 64) * 16);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const int row = rsub + 32 * i;             // channel d
+      const int key = kv0 + cs * 8;
+      const bf16_t* src = (row < DH && key < Nk) ? Vt + (int64_t)row * ldvt + key
+                                                 : (const bf16_t*)attn_zero_page;
+      glds16(src, sV + (wave * 8 + 32 * i) * 128);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+      const char* krow = sK + (32 * kt + r) * KROW + h * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(krow + ks * 32);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    if (kv0 + KB > Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kv0 + 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= Nk) s[kt][e] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[kt][e] * scale_log2e - m_new);
+        psum += pv;
+        pf[kt][e >> 3][e & 7] = (__bf16)pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const char* vrow = sV + (32 * dt + r) * 128 + 8 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const int c1 = 4 * kt + 2 * ss;
+          const uint2 lo = *(const uint2*)(vrow + ((c1 ^ rswz) << 4));
+          const uint2 hi = *(const uint2*)(vrow + (((c1 + 1) ^ rswz) << 4));
+          const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, pk);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < Nq) {
+    bf16_t* op = O + (int64_t)q * ldo;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * dt + 8 * g + 4 * h;
+        if (d0 < DH) {
+          u16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(o[dt][4 * g + e] * inv);
+          *(u16x4*)(op + d0) = ov;
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,
                                                            bf16_t* __restrict__ P, int cols,
                                                            int64_t ld_in, int64_t ld_out) {
@@ -201,18 +360,27 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
                                    int ldo, int64_t sq, int64_t sk, int64_t svt, int64_t so,
                                    float scale, void* stream) {
   LBMK_REQUIRE(q && k && vt && o, "flash_attn: null pointer");
-  LBMK_REQUIRE(Dh == 64, "flash_attn: head_dim %d not supported (64 only)", Dh);
+  LBMK_REQUIRE(Dh == 64 || Dh == 40 || Dh == 80 || Dh == 160,
+               "flash_attn: head_dim %d not supported (40, 64, 80, 160)", Dh);
   LBMK_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "flash_attn: sizes");
-  LBMK_REQUIRE(Nk % 8 == 0, "flash_attn: Nk=%d must be a multiple of 8", Nk);
   LBMK_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "flash_attn: leading dims");
   LBMK_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && svt % 8 == 0 && so % 4 == 0, "flash_attn: batch strides");
-  LBMK_REQUIRE(ldq >= H * Dh && ldk >= H * Dh && ldo >= H * Dh && ldvt >= Nk, "flash_attn: leading dims too small");
+  // V^T rows are read in 8-key chunks: the row stride must cover Nk rounded up to 8 (padding finite)
+  LBMK_REQUIRE(ldq >= H * Dh && ldk >= H * Dh && ldo >= H * Dh && ldvt >= (Nk + 7) / 8 * 8,
+               "flash_attn: leading dims too small");
   LBMK_REQUIRE(lbmk_aligned(q, 16) && lbmk_aligned(k, 16) && lbmk_aligned(vt, 16) && lbmk_aligned(o, 8),
                "flash_attn: misaligned pointer");
   dim3 grid((Nq + QB - 1) / QB, H, B);
-  hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
-                     (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq,
-                     sk, svt, so, scale * 1.4426950408889634f);
+  hipStream_t s = (hipStream_t)stream;
+  const float sl2 = scale * 1.4426950408889634f;
+#define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2
+  switch (Dh) {
+    case 64: hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 40: hipLaunchKernelGGL(flash_fwd_gen_kernel<40>, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 80: hipLaunchKernelGGL(flash_fwd_gen_kernel<80>, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 160: hipLaunchKernelGGL(flash_fwd_gen_kernel<160>, grid, dim3(256), 0, s, FA_ARGS); break;
+  }
+#undef FA_ARGS
   return lbmk_check_launch("flash_attn");
 }
 

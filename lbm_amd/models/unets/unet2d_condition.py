@@ -82,15 +82,25 @@ class Attention(nn.Module, _Cached):
         """xn: normalised tokens [B, N, C]; ctx None => self-attention over xn (the reference passes
         encoder_hidden_states=None with cross_attention_dim == C, so attn2 is a self-attention too);
         residual: tensor added to the output projection in the GEMM epilogue."""
-        if ctx is not None:
-            raise NotImplementedError("cross-attention context (lighting tokens) is not implemented on the HIP path yet")
-        if self.dim_head != 64:
-            raise NotImplementedError(f"flash attention kernel supports head_dim 64 only (got {self.dim_head})")
+        if self.dim_head not in (40, 64, 80, 160):
+            raise NotImplementedError(f"flash attention kernels cover head_dim 40/64/80/160 (got {self.dim_head})")
         C = self.inner_dim
-        qk = ops.linear(xn, fused_rows(self, "qk", [self.to_q, self.to_k], bias=self.to_q.bias is not None))
-        wv, bv = self._v_weight()
-        vt = ops.gemm_nt(wv, xn, bias_m=bv)            # [B, C, N]
-        o = ops.flash_attn(qk[..., :C], qk[..., C:], vt, self.heads, self.dim_head)
+        if ctx is None:
+            qk = ops.linear(xn, fused_rows(self, "qk", [self.to_q, self.to_k], bias=self.to_q.bias is not None))
+            wv, bv = self._v_weight()
+            vt = ops.gemm_nt(wv, xn, bias_m=bv)            # [B, C, N]
+            o = ops.flash_attn(qk[..., :C], qk[..., C:], vt, self.heads, self.dim_head)
+        else:
+            # a handful of context tokens (lighting parameters): K / V come from ctx, keys past the
+            # token count are masked in the kernel; V^T is padded to a multiple of 8 keys with zeros
+            ctx = ctx.to(torch.bfloat16).contiguous()
+            M = ctx.shape[1]
+            q = self.to_q(xn)
+            k = self.to_k(ctx)
+            v = self.to_v(ctx)                              # [B, M, C]
+            vt = torch.zeros(ctx.shape[0], C, (M + 7) // 8 * 8, dtype=torch.bfloat16, device=ctx.device)
+            vt[:, :, :M] = v.transpose(1, 2)
+            o = ops.flash_attn(q, k, vt, self.heads, self.dim_head)
         return self.to_out[0](o, residual=residual)
 
 

@@ -230,6 +230,26 @@ def test_flash_attn_d64(ops, cuda, gen, Nq, Nk):
     assert rel_l2(o, ref) < 6e-3
 
 
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("Nq,Nk", [(256, 256), (200, 136), (64, 5)])
+def test_flash_attn_other_head_dims(ops, cuda, gen, D, Nq, Nk):
+    """head dims of the SD1.5-style UNet (8 heads over 320/640/1280 channels) and the 5-token
+    lighting cross-attention (keys past Nk masked, V^T padded to 8 keys)."""
+    B, H = 2, 2
+    q = randbf(gen, B, Nq, H * D)
+    k = randbf(gen, B, Nk, H * D)
+    v = randbf(gen, B, Nk, H * D)
+    nkp = (Nk + 7) // 8 * 8
+    vt = torch.zeros(B, H * D, nkp, dtype=BF)
+    vt[:, :, :Nk] = v.permute(0, 2, 1)
+    o = ops.flash_attn(q.to(cuda), k.to(cuda), vt.to(cuda), H, D)
+    qh = q.float().view(B, Nq, H, D).transpose(1, 2)
+    kh = k.float().view(B, Nk, H, D).transpose(1, 2)
+    vh = v.float().view(B, Nk, H, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, H * D)
+    assert rel_l2(o, ref) < 6e-3
+
+
 def test_flash_attn_online_rescale(ops, cuda, gen):
     # a spiked key late in the sequence forces the running max to jump after many tiles
     B, H, D, N = 1, 1, 64, 512

@@ -91,6 +91,42 @@ def test_unet_concat_conditioning(cuda):
     assert rel_l2(out, ref) < 1e-2
 
 
+SD15_STYLE = dict(
+    in_channels=12, out_channels=4,
+    down_block_types=["CrossAttnDownBlock2D", "DownBlock2D"], up_block_types=["UpBlock2D", "CrossAttnUpBlock2D"],
+    block_out_channels=[320, 640], layers_per_block=1, transformer_layers_per_block=1, attention_head_dim=8,
+    use_linear_projection=False)
+
+
+@pytest.mark.parametrize("mode", ["relight_self_attn", "filllight_cross_attn"])
+def test_unet_sd15_style_matches_oracle(cuda, mode):
+    """The SD1.5-style family of src/lbm/inference/relight.py:61-120: 8 heads (head_dim 40 at 320
+    channels), 1x1-conv projections, concat conditioning; attn2 is a self-attention when
+    cross_attention_dim equals the channel count (relight) and attends to 5 lighting tokens of
+    width 768 otherwise (filllight)."""
+    from lbm_amd.models.unets import DiffusersUNet2DCondWrapper
+    from oracle import diffusers_ref as dr
+    cad = [320, 640] if mode == "relight_self_attn" else 768
+    cfg = dict(SD15_STYLE, cross_attention_dim=cad)
+    torch.manual_seed(4)
+    m = DiffusersUNet2DCondWrapper(**cfg).to(BF)
+    sd = f32_state(m)
+    m = m.to(cuda).eval()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 4, 16, 16, generator=g).to(BF)
+    c = torch.randn(2, 8, 16, 16, generator=g).to(BF)
+    ts = torch.tensor([750.0, 250.0])
+    cond = {"concat": c.to(cuda)}
+    ctx = None
+    if mode == "filllight_cross_attn":
+        ctx = torch.randn(2, 5, 768, generator=g).to(BF)
+        cond["crossattn"] = ctx.to(cuda)
+    ref = dr.unet_forward(sd, cfg, torch.cat([x, c], 1).float(), ts, None if ctx is None else ctx.float())
+    with torch.no_grad():
+        out = m(sample=x.to(cuda), timestep=ts.to(cuda), conditioning={"cond": cond})
+    assert rel_l2(out, ref) < 1e-2
+
+
 def test_vae_encode_decode_matches_oracle(vae, cuda):
     from oracle import diffusers_ref as dr
     w, sd = vae
