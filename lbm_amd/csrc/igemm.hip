@@ -17,7 +17,97 @@
 
 __device__ __attribute__((aligned(16))) uint32_t igemm_zero_page[8];
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF>
+// Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
+// output row / packed column are mbase / nbase.
+template <int MI, int NI>
+__device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (&acc)[MI][NI], int mbase,
+                                               int nbase, int lane, int z) {
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ohw = p.OH * p.OW;
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int64_t zo = (int64_t)z * p.so, zr = (int64_t)z * p.sr;
+  const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
+  const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
+  const bool geglu = p.act == LBMK_ACT_GEGLU;
+  const int n_out = geglu ? (p.N >> 1) : p.N;
+  const bool vec_ok = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
+                      (!res || (p.ldr & 3) == 0) && (!rowvec || (p.rowvec_ld & 3) == 0);
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mbase + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int bimg = rowvec ? m / ohw : 0;
+    const float bm = (p.bias && p.bias_per_m) ? p.bias[m] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int np = nbase + j * 16 + lq * 4;   // packed column of element 0
+      float v[4];
+      int no;                                           // output column of element 0
+      if (geglu) {
+        if (j & 1) continue;
+        if constexpr (NI >= 2) {
+          no = ((nbase + j * 16) >> 1) + lq * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float val = acc[i][j][e] * p.alpha, gate = acc[i][(j + 1) % NI][e] * p.alpha;
+            if (p.bias && np + 16 + e < p.N) { val += p.bias[np + e]; gate += p.bias[np + 16 + e]; }
+            v[e] = val * gelu_erf_f(gate);
+          }
+        } else {
+          continue;
+        }
+      } else {
+        no = np;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = acc[i][j][e] * p.alpha + bm;
+          if (p.bias && !p.bias_per_m && np + e < p.N) val += p.bias[np + e];
+          v[e] = val;
+        }
+      }
+      if (no >= n_out) continue;
+      if (vec_ok) {
+        if (rowvec) {
+          const u16x4 rv = *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(rv.v[e]);
+        }
+        if (res) {
+          const u16x4 rr = *(const u16x4*)(res + (int64_t)m * p.ldr + no);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(rr.v[e]);
+        }
+        if (p.act == LBMK_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+        if (p.out_f32) {
+          float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          u16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
+          *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (no + e >= n_out) break;
+          float val = v[e];
+          if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
+          if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
+          if (p.act == LBMK_ACT_SILU) val = silu_f(val);
+          if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
+          else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
@@ -128,23 +218,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
   };
 
-  // MFMA over one staged 64-deep tile
+  // MFMA over one staged 64-deep tile, software-pipelined inside the wave: a tile is 2*NI steps of
+  // MI MFMAs (one B fragment against all A fragments of a 32-deep k-step).  Each step first issues
+  // the ds_read of the NEXT step's B fragment and, during the first k-step, one share of the second
+  // k-step's A fragments, so LDS latency is covered by the step's own MFMAs; only the first
+  // MI + 1 reads after the barrier are exposed.
   auto compute = [&](const char* buf) {
+    const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
+    const char* pa = buf + rdA;
+    const char* pb = buf + rdB;
+    bf16x8 fa[2][MI], fb[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int off = ((ks * 4 + lq) ^ rd_swz) << 4;
-      bf16x8 fa[MI], fb[NI];
+    for (int i = 0; i < MI; ++i) fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
+    fb[0] = *(const bf16x8*)(pb + off0);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[j] = *(const bf16x8*)(buf + rdB + j * 16 * 128 + off);
+    for (int st = 0; st < 2 * NI; ++st) {
+      const int ks = st / NI, j = st % NI;
+      if (st + 1 < 2 * NI) {
+        const int ks2 = (st + 1) / NI, j2 = (st + 1) % NI;
+        fb[(st + 1) & 1] = *(const bf16x8*)(pb + j2 * 16 * 128 + (ks2 ? off1 : off0));
+      }
+      if (ks == 0) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(buf + rdA + i * 16 * 128 + off);
-      __builtin_amdgcn_s_setprio(1);
+        for (int i = j; i < MI; i += NI) fa[1][i] = *(const bf16x8*)(pa + i * 16 * 128 + off1);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[st & 1], fa[ks][i], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -157,10 +257,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
-      compute(smem + (kt & 1) * STAGE);
+      // ABL != 0: timing-only ablations (1: no loads in the loop, 2: no MFMA work, 3: no loads and
+      // no barrier); results are invalid
+      if (ABL != 1 && ABL != 3 && kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+      if (ABL != 2) compute(smem + (kt & 1) * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (ABL != 3) __syncthreads();
     }
   } else {
     for (int kt = 0; kt < nkt; ++kt) {
@@ -172,88 +274,161 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     }
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------
-  const int64_t zo = (int64_t)z * p.so, zr = (int64_t)z * p.sr;
-  const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
-  const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
-  const bool geglu = p.act == LBMK_ACT_GEGLU;
-  const int n_out = geglu ? (p.N >> 1) : p.N;
-  const bool vec_ok = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
-                      (!res || (p.ldr & 3) == 0) && (!rowvec || (p.rowvec_ld & 3) == 0);
+  igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
+}
 
+// ------------------------------------------------------------------------------------------------
+// Deep-prefetch variant: 32-deep K tiles in NSTAGE LDS stages.  NSTAGE-1 tiles of LDS-DMA loads are
+// in flight while one is computed; a counted s_waitcnt vmcnt(N) retires only the oldest tile and a raw
+// s_barrier (no vmcnt(0) drain) publishes it, so the L2 -> LDS path never idles between tiles.
+// LDS rows are 64 bytes (4 slots of 16 B, 4 rows per 256-byte bank row); the slot permutation
+// f(g) = [0,2,3,1][(row >> 2) & 3] makes every 16-lane ds_read_b128 group conflict-free.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ int swz32(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_k32_kernel(const lbmk_igemm_desc p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int NT = 64 * NW;
+  constexpr int RPP = NT / 4;                   // rows staged per LDS-DMA instruction of the block
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int AI = BM / RPP, BI = BN / RPP;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int LPT = AI + BI;                  // LDS-DMA loads per thread per tile
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile shape");
+  static_assert((NSTAGE - 2) * LPT <= 15, "vmcnt immediates");
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int wgid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tile_n = wgid % tiles_n;
+  const int tile_m = wgid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z * p.sw;
+
+  const int slot = t & 3, rsub = t >> 2;
+  const int kk = (slot ^ swz32(rsub)) * 8;
+  const int ohw = p.OH * p.OW;
+  const int IHe = p.up2 ? 2 * p.IH : p.IH;
+  const int IWe = p.up2 ? 2 * p.IW : p.IW;
+
+  int a_by[AI], a_bx[AI], a_boff[AI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WM + i * 16 + lr;
-    if (m >= p.M) continue;
-    const int bimg = rowvec ? m / ohw : 0;
-    const float bm = (p.bias && p.bias_per_m) ? p.bias[m] : 0.f;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int np = n0 + wn * WN + j * 16 + lq * 4;   // packed column of element 0
-      float v[4];
-      int no;                                           // output column of element 0
-      if (geglu) {
-        if (j & 1) continue;
-        if constexpr (NI >= 2) {
-          no = ((n0 + wn * WN + j * 16) >> 1) + lq * 4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val = acc[i][j][e] * p.alpha, gate = acc[i][(j + 1) % NI][e] * p.alpha;
-            if (p.bias && np + 16 + e < p.N) { val += p.bias[np + e]; gate += p.bias[np + 16 + e]; }
-            v[e] = val * gelu_erf_f(gate);
-          }
-        } else {
-          continue;
-        }
-      } else {
-        no = np;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float val = acc[i][j][e] * p.alpha + bm;
-          if (p.bias && !p.bias_per_m && np + e < p.N) val += p.bias[np + e];
-          v[e] = val;
-        }
-      }
-      if (no >= n_out) continue;
-      if (vec_ok) {
-        if (rowvec) {
-          const u16x4 rv = *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(rv.v[e]);
-        }
-        if (res) {
-          const u16x4 rr = *(const u16x4*)(res + (int64_t)m * p.ldr + no);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(rr.v[e]);
-        }
-        if (p.act == LBMK_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-        }
-        if (p.out_f32) {
-          float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
-          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          u16x4 ov;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
-          *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (no + e >= n_out) break;
-          float val = v[e];
-          if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
-          if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
-          if (p.act == LBMK_ACT_SILU) val = silu_f(val);
-          if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
-          else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
-        }
-      }
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + rsub + RPP * i;
+    if (m < p.M) {
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_by[i] = oy * p.stride - p.pad_t;
+      a_bx[i] = ox * p.stride - p.pad_l;
+      a_boff[i] = b * p.IH * p.IW;
+    } else {
+      a_by[i] = -(1 << 28);
+      a_bx[i] = 0;
+      a_boff[i] = 0;
     }
   }
+  const bf16_t* w_ptr[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int n = n0 + rsub + RPP * i;
+    w_ptr[i] = n < p.N ? W + (int64_t)n * p.Kp + kk : nullptr;
+  }
+  int ch = kk, tap = 0;
+  while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+  const int ntaps = p.KH * p.KW;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rd_off = (lq ^ swz32(lr)) << 4;
+  const int rdA = (wm * WM + lr) * 64 + rd_off;
+  const int rdB = BM * 64 + (wn * WN + lr) * 64 + rd_off;
+
+  auto stage = [&](int kt, char* buf) {
+    int kh = 0, kw = 0;
+    if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
+    const bool tap_ok = tap < ntaps;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int iy = a_by[i] + kh, ix = a_bx[i] + kw;
+      const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
+      if (p.up2) { iy >>= 1; ix >>= 1; }
+      const bf16_t* src = ok
+          ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
+          : (const bf16_t*)igemm_zero_page;
+      glds16(src, buf + (wave * 16 + RPP * i) * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const bf16_t* src = (w_ptr[i] && (kt << 5) + kk < p.K) ? w_ptr[i] + (kt << 5)
+                                                               : (const bf16_t*)igemm_zero_page;
+      glds16(src, buf + BM * 64 + (wave * 16 + RPP * i) * 64);
+    }
+    ch += 32;
+    while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+  };
+
+  auto compute = [&](const char* buf) {
+    const char* pa = buf + rdA;
+    const char* pb = buf + rdB;
+    bf16x8 fa[MI], fb[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(pa + i * 16 * 64);
+    fb[0] = *(const bf16x8*)pb;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (j + 1 < NI) fb[(j + 1) & 1] = *(const bf16x8*)(pb + (j + 1) * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkt = (p.K + 31) >> 5;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nkt) stage(s, smem + s * STAGE);
+  int rd_stage = 0, wr_stage = NSTAGE - 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // tiles issued after tile kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
+    const int ahead = nkt - 1 - kt;
+    if (ahead >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * LPT>();
+    else if (NSTAGE > 3 && ahead == NSTAGE - 3) wait_vmcnt<(NSTAGE > 3 ? NSTAGE - 3 : 0) * LPT>();
+    else if (NSTAGE > 4 && ahead == NSTAGE - 4) wait_vmcnt<(NSTAGE > 4 ? NSTAGE - 4 : 0) * LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // stage wr_stage was read by tile kt-1, which every wave finished before this barrier
+    if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1, smem + wr_stage * STAGE);
+    compute(smem + rd_stage * STAGE);
+    rd_stage = rd_stage + 1 == NSTAGE ? 0 : rd_stage + 1;
+    wr_stage = wr_stage + 1 == NSTAGE ? 0 : wr_stage + 1;
+  }
+  igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
 }
+
 
 // ---- host side ------------------------------------------------------------------------------
 namespace {
@@ -261,14 +436,22 @@ struct TileCfg { int bm, bn; };
 const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64}, {256, 256}, {256, 128},
                           {256, 256},    // 7: 256x256 with 16 waves (64x64 per wave)
                           {512, 128},    // 8: 16 waves, for N = 128 layers
-                          {256, 128}};   // 9: 16 waves (64x32 per wave)
+                          {256, 128},    // 9: 16 waves (64x32 per wave)
+                          {256, 256},    // 10: 16 waves, 32-deep K tiles, 4 stages, counted vmcnt
+                          {256, 256}};   // 11: same, 5 stages
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int BM, int BN, int WMs, int WNs, bool DBUF>
+template <int BM, int BN, int WMs, int WNs, bool DBUF, int ABL = 0>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL>), grid, dim3(64 * WMs * WNs), 0, s, d);
+}
+template <int BM, int BN, int WMs, int WNs, int NSTAGE>
+void launch_k32(const lbmk_igemm_desc& d, hipStream_t s) {
+  const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
+  hipLaunchKernelGGL((igemm_k32_kernel<BM, BN, WMs, WNs, NSTAGE>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
 
@@ -325,6 +508,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       else if (d.N >= 64 && blocks512 >= 600) tile = 8;
     }
   }
+  if (tile == 100) { launch<256, 256, 4, 4, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 102) { launch<256, 256, 4, 4, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 101) { launch<256, 256, 4, 4, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
   hipStream_t s = (hipStream_t)stream;
@@ -339,6 +525,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 7: launch<256, 256, 4, 4, true>(d, s); break;
     case 8: launch<512, 128, 8, 2, true>(d, s); break;
     case 9: launch<256, 128, 4, 4, true>(d, s); break;
+    case 10: launch_k32<256, 256, 4, 4, 4>(d, s); break;
+    case 11: launch_k32<256, 256, 4, 4, 5>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
