@@ -60,6 +60,8 @@ typedef struct lbmk_igemm_desc {
   int32_t batch;        /* independent problems (grid.z); strides below in elements    */
   int64_t sa, sw, so, sr;
   int32_t tile;         /* -1 auto, else index into the tile table (see lbmk_igemm_tiles) */
+  int32_t k_order;      /* 0: k = tap*Cin + c;  1 (Cin % 64 == 0): k = (c/64)*KH*KW*64 + tap*64 + c%64,
+                           i.e. the 9 taps of one 64-channel chunk are consecutive K tiles (L1 reuse) */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);

@@ -44,7 +44,7 @@ class IgemmDesc(C.Structure):
         ("alpha", f32),
         ("batch", i32),
         ("sa", i64), ("sw", i64), ("so", i64), ("sr", i64),
-        ("tile", i32),
+        ("tile", i32), ("k_order", i32),
     ]
 
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   auto stage = [&](int kt, char* buf) {
     int kh = 0, kw = 0;
     if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-    const bool tap_ok = tap < ntaps;
+    const bool tap_ok = tap < ntaps && ch < p.Cin;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int iy = a_by[i] + kh, ix = a_bx[i] + kw;
@@ -214,8 +214,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
         glds16(src, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
       }
     }
-    ch += 64;
-    while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    if (p.k_order) {
+      if (++tap == ntaps) { tap = 0; ch += 64; }
+    } else {
+      ch += 64;
+      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    }
   };
 
   // MFMA over one staged 64-deep tile, software-pipelined inside the wave: a tile is 2*NI steps of
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_k32_kernel(const
   auto stage = [&](int kt, char* buf) {
     int kh = 0, kw = 0;
     if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-    const bool tap_ok = tap < ntaps;
+    const bool tap_ok = tap < ntaps && ch < p.Cin;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       int iy = a_by[i] + kh, ix = a_bx[i] + kw;
@@ -387,8 +391,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_k32_kernel(const
                                                                : (const bf16_t*)igemm_zero_page;
       glds16(src, buf + BM * 64 + (wave * 16 + RPP * i) * 64);
     }
-    ch += 32;
-    while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    if (p.k_order) {          // chunk-major: (64-channel chunk, tap, 32-channel half)
+      ch += 32;
+      if ((ch & 63) < 32) {   // finished both halves of this (chunk, tap)
+        ch -= 64;
+        if (++tap == ntaps) { tap = 0; ch += 64; }
+      }
+    } else {
+      ch += 32;
+      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    }
   };
 
   auto compute = [&](const char* buf) {
@@ -478,6 +490,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE(d.M % (d.OH * d.OW) == 0, "igemm: M=%d is not a whole number of %dx%d images", d.M, d.OH, d.OW);
   LBMK_REQUIRE((int64_t)(d.M / (d.OH * d.OW)) * d.IH * d.IW < (1LL << 31), "igemm: input pixel count overflows int32");
   LBMK_REQUIRE(d.act >= 0 && d.act <= 2, "igemm: act %d", d.act);
+  LBMK_REQUIRE(d.k_order == 0 || (d.k_order == 1 && d.Cin % 64 == 0), "igemm: k_order %d needs Cin %% 64 == 0", d.k_order);
   LBMK_REQUIRE(d.ldo >= (d.act == LBMK_ACT_GEGLU ? d.N / 2 : d.N), "igemm: ldo=%d too small", d.ldo);
   LBMK_REQUIRE(lbmk_aligned(d.out, d.out_f32 ? 16 : 8), "igemm: out misaligned");
   LBMK_REQUIRE(!d.residual || lbmk_aligned(d.residual, 8), "igemm: residual misaligned");
@@ -510,6 +523,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   }
   if (tile == 100) { launch<256, 256, 4, 4, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 102) { launch<256, 256, 4, 4, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 110) { launch<512, 128, 8, 2, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 111) { launch<512, 128, 8, 2, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 112) { launch<512, 128, 8, 2, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 101) { launch<256, 256, 4, 4, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");

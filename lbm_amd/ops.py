@@ -59,6 +59,7 @@ class PackedWeight:
     KW: int
     geglu: bool = False
     alg_nk: int = 0                 # un-padded N*K of the layer (algorithmic MACs per output row)
+    k_order: int = 0                # 1: K runs chunk-major (64 channels x all taps), see lbmk_igemm_desc.k_order
 
 
 def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
@@ -73,13 +74,18 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pack
     Kp = ceil_to(K, 64)
     w = torch.zeros(N, KH * KW, cin_p, dtype=bf16, device=weight.device)
     w[:, :, :Cin] = weight.detach().permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(bf16)
+    # 3x3 layers with whole 64-channel chunks: make the 9 taps of one chunk consecutive K tiles, so
+    # successive tiles re-read nearly the same (one-pixel shifted) input lines
+    k_order = 1 if (KH * KW > 1 and cin_p % 64 == 0) else 0
+    if k_order:
+        w = w.reshape(N, KH * KW, cin_p // 64, 64).permute(0, 2, 1, 3)
     packed = torch.zeros(n_p, Kp, dtype=bf16, device=weight.device)
     packed[:N, :K] = w.reshape(N, K)
     b = None
     if bias is not None:
         b = torch.zeros(n_p, dtype=torch.float32, device=weight.device)
         b[:N] = bias.detach().float()
-    return PackedWeight(packed.contiguous(), b, n_p, K, Kp, cin_p, KH, KW, alg_nk=N * KH * KW * Cin)
+    return PackedWeight(packed.contiguous(), b, n_p, K, Kp, cin_p, KH, KW, alg_nk=N * KH * KW * Cin, k_order=k_order)
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
@@ -182,6 +188,7 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
     d.out_f32, d.bias_per_m, d.alpha = 0, 0, 1.0
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
+    d.k_order = pw.k_order
     _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
     return out
 
