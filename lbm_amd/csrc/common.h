@@ -58,4 +58,6 @@ void lbmk_set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 int lbmk_check_launch(const char* what);
+// compute units of the current device (cached per device; 256 when the query fails)
+int lbmk_num_cus(void);
 static inline bool lbmk_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }

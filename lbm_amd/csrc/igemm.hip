@@ -16,71 +16,93 @@
 #include "common.h"
 
 __device__ __attribute__((aligned(16))) uint32_t igemm_zero_page[8];
+__device__ unsigned long long igemm_dbg[65536 * 6];  // TEMP timing instrumentation (ABL == 5)
+#define DBG_T(i) do { if (ABL == 5 && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
 
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
 // output row / packed column are mbase / nbase.
+// Loads are batched ahead of the stores on purpose: `out` may alias anything as far as the compiler
+// knows, so a load written after a store waits for it.  The bias of all NI column groups is read once,
+// and the residual / rowvec operands of row group i+1 are in flight while row group i is stored.
 template <int MI, int NI>
 __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (&acc)[MI][NI], int mbase,
                                                int nbase, int lane, int z) {
   const int lr = lane & 15, lq = lane >> 4;
   const int ohw = p.OH * p.OW;
-  // ---- epilogue ---------------------------------------------------------------------------
   const int64_t zo = (int64_t)z * p.so, zr = (int64_t)z * p.sr;
   const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
   const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
+  const float* __restrict__ bias = p.bias;
   const bool geglu = p.act == LBMK_ACT_GEGLU;
   const int n_out = geglu ? (p.N >> 1) : p.N;
   const bool vec_ok = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
                       (!res || (p.ldr & 3) == 0) && (!rowvec || (p.rowvec_ld & 3) == 0);
 
+  // fold alpha and the bias into the accumulators in place (the bias registers die right here)
+  {
+    float bv[NI][4];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = mbase + i * 16 + lr;
-    if (m >= p.M) continue;
-    const int bimg = rowvec ? m / ohw : 0;
-    const float bm = (p.bias && p.bias_per_m) ? p.bias[m] : 0.f;
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int np = nbase + j * 16 + lq * 4;   // packed column of element 0
-      float v[4];
-      int no;                                           // output column of element 0
-      if (geglu) {
-        if (j & 1) continue;
-        if constexpr (NI >= 2) {
-          no = ((nbase + j * 16) >> 1) + lq * 4;
+      for (int e = 0; e < 4; ++e) {
+        const int n = nbase + j * 16 + lq * 4 + e;
+        bv[j][e] = (bias && !p.bias_per_m && n < p.N) ? bias[n] : 0.f;
+      }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val = acc[i][j][e] * p.alpha, gate = acc[i][(j + 1) % NI][e] * p.alpha;
-            if (p.bias && np + 16 + e < p.N) { val += p.bias[np + e]; gate += p.bias[np + 16 + e]; }
-            v[e] = val * gelu_erf_f(gate);
-          }
-        } else {
-          continue;
-        }
-      } else {
-        no = np;
+    for (int i = 0; i < MI; ++i) {
+      const int m = mbase + i * 16 + lr;
+      const float bm = (bias && p.bias_per_m && m < p.M) ? bias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = acc[i][j][e] * p.alpha + bm + bv[j][e];
+    }
+  }
+
+  // output column of element 0 of column group j (GEGLU: value / gate groups alternate, j even is kept)
+  auto out_col = [&](int j) { return geglu ? ((nbase + j * 16) >> 1) + lq * 4 : nbase + j * 16 + lq * 4; };
+
+  if (vec_ok) {
+    const bool has_add = res || rowvec;
+    u16x4 rr[NI], rv[NI];
+    auto fetch = [&](int i) {
+      const int m = mbase + i * 16 + lr;
+      const bool row_ok = m < p.M;
+      const int bimg = (rowvec && row_ok) ? m / ohw : 0;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int no = out_col(j);
+        const bool ok = row_ok && no < n_out;
+        rr[j] = (res && ok) ? *(const u16x4*)(res + (int64_t)m * p.ldr + no) : u16x4{{0, 0, 0, 0}};
+        rv[j] = (rowvec && ok) ? *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no) : u16x4{{0, 0, 0, 0}};
+      }
+    };
+    if (has_add) fetch(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (has_add) {
+        // consume the operands of row group i in place, then put the loads of row group i+1 in
+        // flight BEFORE the stores of row group i
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += bf2f(rr[j].v[e]) + bf2f(rv[j].v[e]);
+        if (i + 1 < MI) fetch(i + 1);
+      }
+      const int m = mbase + i * 16 + lr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (geglu && (j & 1)) continue;
+        const int no = out_col(j);
+        if (no >= n_out) continue;
+        float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float val = acc[i][j][e] * p.alpha + bm;
-          if (p.bias && !p.bias_per_m && np + e < p.N) val += p.bias[np + e];
-          v[e] = val;
-        }
-      }
-      if (no >= n_out) continue;
-      if (vec_ok) {
-        if (rowvec) {
-          const u16x4 rv = *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(rv.v[e]);
-        }
-        if (res) {
-          const u16x4 rr = *(const u16x4*)(res + (int64_t)m * p.ldr + no);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(rr.v[e]);
-        }
-        if (p.act == LBMK_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          v[e] = acc[i][j][e];
+          if (geglu) v[e] *= gelu_erf_f(acc[i][(j + 1) % NI][e]);
+          else if (p.act == LBMK_ACT_SILU) v[e] = silu_f(v[e]);
         }
         if (p.out_f32) {
           float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
@@ -91,24 +113,43 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
           *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
         }
-      } else {
+      }
+    }
+    return;
+  }
+
+  // element-wise path for shapes whose rows are not 8-byte aligned (never the case for packed layers)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (no + e >= n_out) break;
-          float val = v[e];
-          if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
-          if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
-          if (p.act == LBMK_ACT_SILU) val = silu_f(val);
-          if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
-          else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
-        }
+  for (int i = 0; i < MI; ++i) {
+    const int m = mbase + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int bimg = rowvec ? m / ohw : 0;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (geglu && (j & 1)) continue;
+      const int no = out_col(j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (no + e >= n_out) break;
+        float val = acc[i][j][e];
+        if (geglu) val *= gelu_erf_f(acc[i][(j + 1) % NI][e]);
+        if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
+        if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
+        if (p.act == LBMK_ACT_SILU) val = silu_f(val);
+        if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
+        else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
       }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0>
+// PERSIST (double-buffered tiles only): the grid is one workgroup per CU slot and each workgroup walks
+// tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  The first K-tile of the next output tile is issued
+// before the epilogue of the current one, so neither the workgroup turnover of a 16-wave / 160 KB-LDS
+// block nor the load latency of its first stage is paid once per output tile.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbmk_igemm_desc p) {
+  static_assert(!PERSIST || DBUF, "persistent tiles are double-buffered");
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
   constexpr int RPP = NT / 8;                   // tile rows staged by one LDS-DMA instruction of the block
@@ -129,15 +170,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   // XCD-aware bijective remap: blocks that share an XCD (same blockIdx % 8) get
   // consecutive tiles, so the column tiles of one row panel hit the same L2.
   const int tiles_n = (p.N + BN - 1) / BN;
-  int wgid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
+  // number of (virtual) workgroups of the remap: every output tile, also when fewer blocks walk them
+  const int nwg = PERSIST ? tiles_n * ((p.M + BM - 1) / BM) : (int)gridDim.x;
+  int m0, n0;
+  auto tile_origin = [&](int orig) __attribute__((always_inline)) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int tile_n = wgid % tiles_n;
-  const int tile_m = wgid / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tile_n = wgid % tiles_n;
+    const int tile_m = wgid / tiles_n;
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+  };
+  int vblock = blockIdx.x;
+  DBG_T(0);
+  tile_origin(vblock);
 
   const int z = blockIdx.z;
   const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
@@ -153,31 +199,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const bool b_loader = (BN >= RPP) || (t < BN * 8);
 
   int a_by[AI], a_bx[AI], a_boff[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + rsub + RPP * i;
-    if (m < p.M) {
-      const int b = m / ohw, rem = m - b * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_by[i] = oy * p.stride - p.pad_t;
-      a_bx[i] = ox * p.stride - p.pad_l;
-      a_boff[i] = b * p.IH * p.IW;
-    } else {
-      a_by[i] = -(1 << 28);
-      a_bx[i] = 0;
-      a_boff[i] = 0;
-    }
-  }
   const bf16_t* w_ptr[BI];
+  int ch, tap;   // running (tap, channel) of this thread's 8-element chunk
+  // staging state of the tile whose origin is (m0, n0)
+  auto tile_setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int n = n0 + rsub + RPP * i;
-    w_ptr[i] = (n < p.N && b_loader) ? W + (int64_t)n * p.Kp + kk : nullptr;
-  }
-
-  // running (tap, channel) of this thread's 8-element chunk
-  int ch = kk, tap = 0;
-  while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + rsub + RPP * i;
+      if (m < p.M) {
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        a_by[i] = oy * p.stride - p.pad_t;
+        a_bx[i] = ox * p.stride - p.pad_l;
+        a_boff[i] = b * p.IH * p.IW;
+      } else {
+        a_by[i] = -(1 << 28);
+        a_bx[i] = 0;
+        a_boff[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int n = n0 + rsub + RPP * i;
+      w_ptr[i] = (n < p.N && b_loader) ? W + (int64_t)n * p.Kp + kk : nullptr;
+    }
+    ch = kk;
+    tap = 0;
+    while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+  };
+  tile_setup();
   const int ntaps = p.KH * p.KW;
 
   f32x4 acc[MI][NI];
@@ -192,7 +242,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const int rdB = BM * 128 + (wn * WN + lr) * 128;
 
   // issue the LDS-DMA loads of K-tile kt into stage buffer `buf`, then advance (tap, ch)
-  auto stage = [&](int kt, char* buf) {
+  auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
     int kh = 0, kw = 0;
     if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
     const bool tap_ok = tap < ntaps && ch < p.Cin;
@@ -227,7 +277,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   // the ds_read of the NEXT step's B fragment and, during the first k-step, one share of the second
   // k-step's A fragments, so LDS latency is covered by the step's own MFMAs; only the first
   // MI + 1 reads after the barrier are exposed.
-  auto compute = [&](const char* buf) {
+  auto compute = [&](const char* buf) __attribute__((always_inline)) {
     const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
     const char* pa = buf + rdA;
     const char* pb = buf + rdB;
@@ -253,13 +303,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   };
 
   const int nkt = (p.K + 63) >> 6;
-  if constexpr (DBUF) {
+  if constexpr (PERSIST) {
+    stage(0, smem);
+    while (true) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+        compute(smem + (kt & 1) * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      // every wave is past the last barrier: both stage buffers are free for the next tile
+      const int cm0 = m0, cn0 = n0;
+      vblock += gridDim.x;
+      const bool more = vblock < nwg;
+      if (more) {
+        tile_origin(vblock);
+        tile_setup();
+        stage(0, smem);
+      }
+      igemm_epilogue<MI, NI>(p, acc, cm0 + wm * WM, cn0 + wn * WN, lane, z);
+      if (!more) return;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else if constexpr (DBUF) {
     // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
     // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
     // wave has finished when it passed the barrier that ended iteration kt-1.
+    DBG_T(1);
     stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DBG_T(2);
     for (int kt = 0; kt < nkt; ++kt) {
       // ABL != 0: timing-only ablations (1: no loads in the loop, 2: no MFMA work, 3: no loads and
       // no barrier); results are invalid
@@ -278,7 +357,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     }
   }
 
+  DBG_T(3);
   igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
+  if (ABL == 5) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,7 +531,9 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {512, 128},    // 8: 16 waves, for N = 128 layers
                           {256, 128},    // 9: 16 waves (64x32 per wave)
                           {256, 256},    // 10: 16 waves, 32-deep K tiles, 4 stages, counted vmcnt
-                          {256, 256}};   // 11: same, 5 stages
+                          {256, 256},    // 11: same, 5 stages
+                          {256, 256},    // 12: tile 7, persistent workgroups
+                          {512, 128}};   // 13: tile 8, persistent workgroups
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int BM, int BN, int WMs, int WNs, bool DBUF, int ABL = 0>
@@ -459,6 +542,14 @@ void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
+// one workgroup per CU (16 waves, >= 128 KB of LDS each), walking the output tiles
+template <int BM, int BN, int WMs, int WNs>
+void launch_persist(const lbmk_igemm_desc& d, hipStream_t s) {
+  const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
+  const int nt = tm * tn;
+  dim3 grid((unsigned)(nt < lbmk_num_cus() ? nt : lbmk_num_cus()), 1, (unsigned)d.batch);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+}
 template <int BM, int BN, int WMs, int WNs, int NSTAGE>
 void launch_k32(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
@@ -466,6 +557,10 @@ void launch_k32(const lbmk_igemm_desc& d, hipStream_t s) {
   hipLaunchKernelGGL((igemm_k32_kernel<BM, BN, WMs, WNs, NSTAGE>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
+
+extern "C" int lbmk_debug_igemm_times(unsigned long long* host, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(igemm_dbg), (size_t)nblocks * 6 * 8);
+}
 
 extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
   for (int i = 0; i < kNumTiles && i < cap; ++i) { bm[i] = kTiles[i].bm; bn[i] = kTiles[i].bn; }
@@ -526,6 +621,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 110) { launch<512, 128, 8, 2, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 111) { launch<512, 128, 8, 2, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 112) { launch<512, 128, 8, 2, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 115) { launch<512, 128, 8, 2, true, 5>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 116) { launch<256, 256, 4, 4, true, 5>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 101) { launch<256, 256, 4, 4, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
@@ -543,6 +640,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 9: launch<256, 128, 4, 4, true>(d, s); break;
     case 10: launch_k32<256, 256, 4, 4, 4>(d, s); break;
     case 11: launch_k32<256, 256, 4, 4, 5>(d, s); break;
+    case 12: launch_persist<256, 256, 4, 4>(d, s); break;
+    case 13: launch_persist<512, 128, 8, 2>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }

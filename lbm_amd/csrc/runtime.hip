@@ -21,5 +21,17 @@ int lbmk_check_launch(const char* what) {
   return LBMK_OK;
 }
 
+int lbmk_num_cus(void) {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 extern "C" const char* lbmk_last_error(void) { return g_err; }
 extern "C" int lbmk_version(void) { return 1; }
