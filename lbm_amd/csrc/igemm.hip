@@ -198,32 +198,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const int IWe = p.up2 ? 2 * p.IW : p.IW;
   const bool b_loader = (BN >= RPP) || (t < BN * 8);
 
-  int a_by[AI], a_bx[AI], a_boff[AI];
-  const bf16_t* w_ptr[BI];
+  // (by + 1) << 16 | (bx + 1) of the top-left tap of each staged row (0x7fff0000: row past M);
+  // weight rows as 32-bit element offsets from W (-1: row past N) -- both to stay inside the
+  // 128-register budget of a 16-wave workgroup
+  int a_yx[AI], a_boff[AI];
+  int w_off[BI];
   int ch, tap;   // running (tap, channel) of this thread's 8-element chunk
   // staging state of the tile whose origin is (m0, n0)
   auto tile_setup = [&]() __attribute__((always_inline)) {
+    int tt = t;
+    if (PERSIST) asm volatile("" : "+v"(tt));   // recompute per tile instead of keeping it live across the K loop
+    const int rs = PERSIST ? (tt >> 3) : rsub;
+    const int kk_ = PERSIST ? (((tt & 7) ^ ((rs >> 1) & 7)) * 8) : kk;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int m = m0 + rsub + RPP * i;
+      const int m = m0 + rs + RPP * i;
       if (m < p.M) {
         const int b = m / ohw, rem = m - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_by[i] = oy * p.stride - p.pad_t;
-        a_bx[i] = ox * p.stride - p.pad_l;
+        a_yx[i] = ((oy * p.stride - p.pad_t + 1) << 16) | (ox * p.stride - p.pad_l + 1);
         a_boff[i] = b * p.IH * p.IW;
       } else {
-        a_by[i] = -(1 << 28);
-        a_bx[i] = 0;
+        a_yx[i] = 0x7fff0000;
         a_boff[i] = 0;
       }
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int n = n0 + rsub + RPP * i;
-      w_ptr[i] = (n < p.N && b_loader) ? W + (int64_t)n * p.Kp + kk : nullptr;
+      const int n = n0 + rs + RPP * i;
+      const bool loader = (BN >= RPP) || (tt < BN * 8);
+      w_off[i] = (n < p.N && loader) ? n * p.Kp + kk_ : -1;
     }
-    ch = kk;
+    ch = kk_;
     tap = 0;
     while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
   };
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     const bool tap_ok = tap < ntaps && ch < p.Cin;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int iy = a_by[i] + kh, ix = a_bx[i] + kw;
+      int iy = (a_yx[i] >> 16) - 1 + kh, ix = (a_yx[i] & 0xffff) - 1 + kw;
       const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
       if (p.up2) { iy >>= 1; ix >>= 1; }
       const bf16_t* src = ok
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       if (b_loader) {
-        const bf16_t* src = (w_ptr[i] && (kt << 6) + kk < p.K) ? w_ptr[i] + (kt << 6)
-                                                                 : (const bf16_t*)igemm_zero_page;
+        const bf16_t* src = (w_off[i] >= 0 && (kt << 6) + kk < p.K) ? W + w_off[i] + (kt << 6)
+                                                                      : (const bf16_t*)igemm_zero_page;
         glds16(src, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
       }
     }
@@ -281,6 +287,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
     const char* pa = buf + rdA;
     const char* pb = buf + rdB;
+    if constexpr (PERSIST) {
+      // one set of A fragments: the second k-step's fragment i replaces the first's right after its
+      // last use (frees 4*MI registers for the tile walk state)
+      bf16x8 fa[MI], fb[2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
+      fb[0] = *(const bf16x8*)(pb + off0);
+#pragma unroll
+      for (int st = 0; st < 2 * NI; ++st) {
+        const int ks = st / NI, j = st % NI;
+        if (st + 1 < 2 * NI) {
+          const int ks2 = (st + 1) / NI, j2 = (st + 1) % NI;
+          fb[(st + 1) & 1] = *(const bf16x8*)(pb + j2 * 16 * 128 + (ks2 ? off1 : off0));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[st & 1], fa[i], acc[i][j], 0, 0, 0);
+          if (ks == 0 && j == NI - 1) fa[i] = *(const bf16x8*)(pa + i * 16 * 128 + off1);
+        }
+      }
+      return;
+    }
     bf16x8 fa[2][MI], fb[2];
 #pragma unroll
     for (int i = 0; i < MI; ++i) fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
@@ -576,6 +604,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
   LBMK_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "igemm: Cin=%d must be a multiple of 8", d.Cin);
   LBMK_REQUIRE(d.K == d.KH * d.KW * d.Cin, "igemm: K=%d != KH*KW*Cin", d.K);
+  LBMK_REQUIRE((int64_t)d.N * d.Kp < (1LL << 31), "igemm: weight matrix %d x %d overflows int32 offsets", d.N, d.Kp);
+  LBMK_REQUIRE(d.IH < 32767 && d.IW < 32767 && d.OH * d.stride < 32767 && d.OW * d.stride < 32767, "igemm: image side >= 32767");
   LBMK_REQUIRE(d.Kp >= d.K && d.Kp % 8 == 0, "igemm: Kp=%d (row stride of w) must be a multiple of 8 >= K", d.Kp);
   LBMK_REQUIRE(d.a_cs % 8 == 0 && d.a_coff % 8 == 0 && d.a_coff >= 0 && d.a_coff + d.Cin <= d.a_cs,
                "igemm: channel window off=%d Cin=%d stride=%d", d.a_coff, d.Cin, d.a_cs);
@@ -601,19 +631,23 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
     else {
-      const long blocks128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
-      if (d.N % 128 == 0 || d.N > 1024) tile = 0;
-      else if (d.N % 64 == 0) tile = (d.M >= 65536) ? 4 : 1;
-      else tile = 0;
-      if (tile == 0 && blocks128 < 256 && d.act != LBMK_ACT_GEGLU) tile = 3;
-      // 16-wave double-buffered tiles (one workgroup per CU, 4 waves per SIMD): 256x256 halves the
-      // L2->LDS bytes per FLOP of the 128x128 tile, 512x128 does the same for narrow outputs.
-      // They pay once the grid still fills the 256 CUs a few times over (measured crossover).
-      const long blocks256 = (long)((d.M + 255) / 256) * ((d.N + 255) / 256) * d.batch;
-      const long blocks512 = (long)((d.M + 511) / 512) * ((d.N + 127) / 128) * d.batch;
-      const bool fits256 = ((d.N + 255) / 256) * 256 * 4 <= d.N * 5;   // <= 25 % padded columns
-      if (d.N >= 256 && fits256 && blocks256 >= 600) tile = 7;
-      else if (d.N >= 64 && blocks512 >= 600) tile = 8;
+      // Cost model over the production tiles: workgroups run in rounds of (CUs x resident blocks per
+      // CU); a round costs resident * bm * bn / rate, padded rows / columns included.  `rate` is the
+      // measured full-occupancy throughput of the tile shape (TFLOP/s, mid-size K): the 16-wave
+      // double-buffered tiles move half the L2->LDS bytes per FLOP of the 128x128 tile.
+      struct Cand { int tile, bm, bn, resident; float rate; };
+      static const Cand cands[] = {{7, 256, 256, 1, 1150.f}, {8, 512, 128, 1, 1050.f}, {9, 256, 128, 1, 880.f},
+                                   {0, 128, 128, 2, 800.f},  {1, 128, 64, 3, 700.f},   {3, 64, 64, 5, 450.f}};
+      const int cus = lbmk_num_cus();
+      double best = 1e300;
+      tile = 0;
+      for (const Cand& c : cands) {
+        const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
+        const long slots = (long)cus * c.resident;
+        const long rounds = (blocks + slots - 1) / slots;
+        const double cost = (double)rounds * c.resident * c.bm * c.bn / c.rate;
+        if (cost < best) { best = cost; tile = c.tile; }
+      }
     }
   }
   if (tile == 100) { launch<256, 256, 4, 4, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
