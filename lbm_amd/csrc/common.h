@@ -48,6 +48,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// 16-byte LDS-DMA load through a buffer descriptor over [base, base + bytes): lane l's data lands at
+// lds_wave_base + 16 * l; a byte offset (voff + soff) at or past `bytes` yields zeros.  base / bytes /
+// soff must be wave-uniform.
+__device__ __forceinline__ void buffer_lds16(const void* base, int bytes, unsigned voff, unsigned soff,
+                                             void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000),
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // host side
 void lbmk_set_error(const char* fmt, ...);
 #define LBMK_REQUIRE(cond, ...)            \

@@ -5,10 +5,10 @@
 // A(m,k) is gathered on the fly from an NHWC activation tensor (m = output pixel,
 // k = (kh, kw, c)), so a 3x3 / 1x1 / stride-2 / nearest-x2-upsampled convolution and a
 // plain linear layer are the same kernel.  Both operands are K-contiguous, so both tiles
-// are staged global -> LDS with 16-byte LDS-DMA loads (global_load_lds_dwordx4): the LDS
+// are staged global -> LDS with 16-byte LDS-DMA loads (buffer_load_dwordx4 ... lds): the LDS
 // image is lane-linear, and the bank-conflict swizzle is applied on the per-lane SOURCE
-// address and again on the ds_read_b128 address.  Out-of-image taps, rows past M / N and
-// the K tail read a 16-byte zero page instead of being predicated.
+// offset and again on the ds_read_b128 address.  Out-of-image taps, rows past M / N and
+// the K tail use an offset past the end of the buffer descriptor, which reads as zeros.
 //
 // MFMA orientation: the weight fragment is the A operand and the activation fragment the
 // B operand of v_mfma_f32_16x16x32_bf16, so each lane ends up with 4 consecutive output
@@ -147,7 +147,9 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  The first K-tile of the next output tile is issued
 // before the epilogue of the current one, so neither the workgroup turnover of a 16-wave / 160 KB-LDS
 // block nor the load latency of its first stage is paid once per output tile.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0, bool PERSIST = false>
+// FAST: Cin % 64 == 0 -- every lane of a K-tile is on the same filter tap, so the
+// tap / channel walk is scalar and a load costs three vector ALU instructions.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0, bool PERSIST = false, bool FAST = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbmk_igemm_desc p) {
   static_assert(!PERSIST || DBUF, "persistent tiles are double-buffered");
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
@@ -189,7 +191,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
   const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z * p.sw;
 
-  // ---- per-thread staging coordinates -------------------------------------------------
+  // ---- staging state ---------------------------------------------------------------------
+  // Both operands are fetched with buffer_load_dwordx4 ... lds through a buffer descriptor: the
+  // per-lane address is one 32-bit byte offset, and an offset at or past the descriptor's size
+  // reads zeros, which is how padding taps, rows past M / N and the K tail are produced (no
+  // branches, no 64-bit address arithmetic in the K loop).
   const int slot = t & 7;          // 16-byte slot inside a 128-byte LDS row
   const int rsub = t >> 3;         // row inside an RPP-row group
   const int kk = (slot ^ ((rsub >> 1) & 7)) * 8;   // swizzled k offset inside the 64-wide tile
@@ -197,44 +203,75 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const int IHe = p.up2 ? 2 * p.IH : p.IH;
   const int IWe = p.up2 ? 2 * p.IW : p.IW;
   const bool b_loader = (BN >= RPP) || (t < BN * 8);
+  const int ntaps = p.KH * p.KW;
+  // Cin % 64 == 0: all lanes of a K-tile sit on the same filter tap, so (tap, channel base) is scalar
+  constexpr bool uni = FAST;
+  constexpr unsigned OOB = 0x80000000u;   // descriptors never cover more than 2^31 - 1 bytes
 
-  // (by + 1) << 16 | (bx + 1) of the top-left tap of each staged row (0x7fff0000: row past M);
-  // weight rows as 32-bit element offsets from W (-1: row past N) -- both to stay inside the
-  // 128-register budget of a 16-wave workgroup
-  int a_yx[AI], a_boff[AI];
-  int w_off[BI];
-  int ch, tap;   // running (tap, channel) of this thread's 8-element chunk
+  const int w_bytes = p.N * p.Kp * 2;
+  const bf16_t* a_base;   // descriptor of the A window of the current tile
+  int a_bytes;
+  // a_vo: byte offset of (row, tap 0) from the tile's descriptor base (wraps for rows whose tap 0 is
+  // padding; only sums that land on valid taps are used).  a_mask: bit tap = tap inside the image;
+  // bits 16 / 17 = parity of the tap-0 row / column in the x2-upsampled frame.
+  unsigned a_vo[AI], a_mask[AI], w_vo[BI];
+  int ch, tap;            // general path: (tap, channel) of this thread's 8-element chunk
+  int chb_s = 0, tap_s = 0;   // uniform path: (tap, channel base) of the K-tile
   // staging state of the tile whose origin is (m0, n0)
   auto tile_setup = [&]() __attribute__((always_inline)) {
     int tt = t;
     if (PERSIST) asm volatile("" : "+v"(tt));   // recompute per tile instead of keeping it live across the K loop
     const int rs = PERSIST ? (tt >> 3) : rsub;
     const int kk_ = PERSIST ? (((tt & 7) ^ ((rs >> 1) & 7)) * 8) : kk;
+    // descriptor base: first input row any tap of this tile's first output row can touch
+    const int b0 = m0 / ohw;
+    const int oy0 = (m0 - b0 * ohw) / p.OW;
+    int by0 = oy0 * p.stride - p.pad_t;
+    by0 = by0 < 0 ? 0 : by0;
+    if (p.up2) by0 >>= 1;
+    const int64_t base_pix = (int64_t)b0 * p.IH * p.IW + (int64_t)by0 * p.IW;
+    int64_t rem = ((int64_t)(p.M / ohw) * p.IH * p.IW - base_pix) * p.a_cs * 2;
+    rem = rem > 0x7fffffff ? 0x7fffffff : rem;
+    a_base = A + base_pix * p.a_cs;
+    a_bytes = (int)rem;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int m = m0 + rs + RPP * i;
+      unsigned mask = 0, vo = 0;
       if (m < p.M) {
-        const int b = m / ohw, rem = m - b * ohw;
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_yx[i] = ((oy * p.stride - p.pad_t + 1) << 16) | (ox * p.stride - p.pad_l + 1);
-        a_boff[i] = b * p.IH * p.IW;
-      } else {
-        a_yx[i] = 0x7fff0000;
-        a_boff[i] = 0;
+        const int b = m / ohw, r2 = m - b * ohw;
+        const int oy = r2 / p.OW, ox = r2 - oy * p.OW;
+        const int by = oy * p.stride - p.pad_t, bx = ox * p.stride - p.pad_l;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            if (kh < p.KH && kw < p.KW && (unsigned)(by + kh) < (unsigned)IHe && (unsigned)(bx + kw) < (unsigned)IWe)
+              mask |= 1u << (kh * p.KW + kw);
+        int ry = by, rx = bx;
+        if (p.up2) {
+          mask |= (unsigned)(by & 1) << 16 | (unsigned)(bx & 1) << 17;
+          ry = by >> 1;
+          rx = bx >> 1;
+        }
+        const int pix = (b - b0) * p.IH * p.IW + (ry - by0) * p.IW + rx;
+        vo = (unsigned)(pix * p.a_cs + p.a_coff + (uni ? kk_ : 0)) * 2u;
       }
+      a_vo[i] = vo;
+      a_mask[i] = mask;
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int n = n0 + rs + RPP * i;
-      const bool loader = (BN >= RPP) || (tt < BN * 8);
-      w_off[i] = (n < p.N && loader) ? n * p.Kp + kk_ : -1;
+      w_vo[i] = (unsigned)(n * p.Kp + kk_) * 2u;   // rows past N are past the end of the W descriptor
     }
     ch = kk_;
     tap = 0;
     while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    chb_s = 0;
+    tap_s = 0;
   };
   tile_setup();
-  const int ntaps = p.KH * p.KW;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -247,34 +284,59 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   const int rdA = (wm * WM + lr) * 128;
   const int rdB = BM * 128 + (wn * WN + lr) * 128;
 
-  // issue the LDS-DMA loads of K-tile kt into stage buffer `buf`, then advance (tap, ch)
+  // issue the LDS-DMA loads of K-tile kt into stage buffer `buf`, then advance (tap, channel)
   auto stage = [&](int kt, char* buf) __attribute__((always_inline)) {
-    int kh = 0, kw = 0;
-    if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-    const bool tap_ok = tap < ntaps && ch < p.Cin;
+    if constexpr (FAST) {
+      int kh = 0, kw = 0;
+      if (p.KW == 3) { kh = (tap_s * 11) >> 5; kw = tap_s - kh * 3; }
+      const unsigned bit = 1u << tap_s;
+      const unsigned soff = (unsigned)((p.up2 ? 0 : (kh * p.IW + kw) * p.a_cs) + chb_s) * 2u;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int iy = (a_yx[i] >> 16) - 1 + kh, ix = (a_yx[i] & 0xffff) - 1 + kw;
-      const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
-      if (p.up2) { iy >>= 1; ix >>= 1; }
-      const bf16_t* src = ok
-          ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
-          : (const bf16_t*)igemm_zero_page;
-      glds16(src, buf + (wave * 8 + RPP * i) * 128);
-    }
+      for (int i = 0; i < AI; ++i) {
+        unsigned vo = a_vo[i] + soff;
+        if (p.up2) {   // source pixel of the tap in the x2-upsampled frame: offsets depend on the row / column parity
+          const int dy = (int)(((a_mask[i] >> 16) & 1) + kh) >> 1, dx = (int)(((a_mask[i] >> 17) & 1) + kw) >> 1;
+          vo += (unsigned)((dy * p.IW + dx) * p.a_cs) * 2u;
+        }
+        vo = (a_mask[i] & bit) ? vo : OOB;
+        buffer_lds16(a_base, a_bytes, vo, 0, buf + (wave * 8 + RPP * i) * 128);
+      }
+      // next (tap, channel base); written as selects so both stay in scalar registers
+      const bool tap_major = p.k_order != 0;
+      const int t1 = tap_s + 1, c1 = chb_s + 64;
+      const bool wrap = tap_major ? (t1 == ntaps) : (c1 >= p.Cin);
+      const int nt = tap_major ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
+      const int nc = tap_major ? (wrap ? c1 : chb_s) : (wrap ? 0 : c1);
+      tap_s = nt;
+      chb_s = nc;
+    } else {
+      int kh = 0, kw = 0;
+      if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
+      const bool tap_ok = tap < ntaps && ch < p.Cin;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      if (b_loader) {
-        const bf16_t* src = (w_off[i] >= 0 && (kt << 6) + kk < p.K) ? W + w_off[i] + (kt << 6)
-                                                                      : (const bf16_t*)igemm_zero_page;
-        glds16(src, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
+      for (int i = 0; i < AI; ++i) {
+        int dy = kh, dx = kw;
+        if (p.up2) {
+          dy = (int)(((a_mask[i] >> 16) & 1) + kh) >> 1;
+          dx = (int)(((a_mask[i] >> 17) & 1) + kw) >> 1;
+        }
+        unsigned vo = a_vo[i] + (unsigned)((dy * p.IW + dx) * p.a_cs + ch) * 2u;
+        vo = (tap_ok && ((a_mask[i] >> tap) & 1)) ? vo : OOB;
+        buffer_lds16(a_base, a_bytes, vo, 0, buf + (wave * 8 + RPP * i) * 128);
+      }
+      if (p.k_order) {
+        if (++tap == ntaps) { tap = 0; ch += 64; }
+      } else {
+        ch += 64;
+        while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
       }
     }
-    if (p.k_order) {
-      if (++tap == ntaps) { tap = 0; ch += 64; }
-    } else {
-      ch += 64;
-      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
+    if (b_loader) {
+      const bool k_ok = (kt << 6) + kk < p.K;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        buffer_lds16(W, w_bytes, k_ok ? w_vo[i] : OOB, kt << 7, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
+      }
     }
   };
 
@@ -564,11 +626,16 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {512, 128}};   // 13: tile 8, persistent workgroups
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
+inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
+
 template <int BM, int BN, int WMs, int WNs, bool DBUF, int ABL = 0>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  if (fast_path(d))
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL, false, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  else
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL, false, false>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 // one workgroup per CU (16 waves, >= 128 KB of LDS each), walking the output tiles
 template <int BM, int BN, int WMs, int WNs>
@@ -576,7 +643,10 @@ void launch_persist(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   const int nt = tm * tn;
   dim3 grid((unsigned)(nt < lbmk_num_cus() ? nt : lbmk_num_cus()), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  if (fast_path(d))
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  else
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true, false>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 template <int BM, int BN, int WMs, int WNs, int NSTAGE>
 void launch_k32(const lbmk_igemm_desc& d, hipStream_t s) {
@@ -604,7 +674,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
   LBMK_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "igemm: Cin=%d must be a multiple of 8", d.Cin);
   LBMK_REQUIRE(d.K == d.KH * d.KW * d.Cin, "igemm: K=%d != KH*KW*Cin", d.K);
-  LBMK_REQUIRE((int64_t)d.N * d.Kp < (1LL << 31), "igemm: weight matrix %d x %d overflows int32 offsets", d.N, d.Kp);
+  LBMK_REQUIRE((int64_t)(d.N + 512) * d.Kp < (1LL << 30), "igemm: weight matrix %d x %d overflows 32-bit byte offsets", d.N, d.Kp);
+  LBMK_REQUIRE((int64_t)d.IH * d.IW * d.a_cs * 2 <= (1LL << 30), "igemm: one input image exceeds 1 GiB (32-bit byte offsets)");
   LBMK_REQUIRE(d.IH < 32767 && d.IW < 32767 && d.OH * d.stride < 32767 && d.OW * d.stride < 32767, "igemm: image side >= 32767");
   LBMK_REQUIRE(d.Kp >= d.K && d.Kp % 8 == 0, "igemm: Kp=%d (row stride of w) must be a multiple of 8 >= K", d.Kp);
   LBMK_REQUIRE(d.a_cs % 8 == 0 && d.a_coff % 8 == 0 && d.a_coff >= 0 && d.a_coff + d.Cin <= d.a_cs,
