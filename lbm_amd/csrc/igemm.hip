@@ -15,9 +15,11 @@
 // channels of one pixel (8-byte bf16 stores along the NHWC channel axis).
 #include "common.h"
 
-__device__ __attribute__((aligned(16))) uint32_t igemm_zero_page[8];
-__device__ unsigned long long igemm_dbg[65536 * 6];  // TEMP timing instrumentation (ABL == 5)
-#define DBG_T(i) do { if (ABL == 5 && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116) record six 100 MHz
+// wall-clock stamps per workgroup: start, after set-up, first stage landed, K loop done, epilogue
+// issued, stores drained.  lbmk_debug_igemm_times() copies them out.  No stamp executes otherwise.
+__device__ unsigned long long igemm_dbg[65536 * 6];
+#define DBG_T(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
@@ -143,15 +145,11 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
   }
 }
 
-// PERSIST (double-buffered tiles only): the grid is one workgroup per CU slot and each workgroup walks
-// tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  The first K-tile of the next output tile is issued
-// before the epilogue of the current one, so neither the workgroup turnover of a 16-wave / 160 KB-LDS
-// block nor the load latency of its first stage is paid once per output tile.
 // FAST: Cin % 64 == 0 -- every lane of a K-tile is on the same filter tap, so the
 // tap / channel walk is scalar and a load costs three vector ALU instructions.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, int ABL = 0, bool PERSIST = false, bool FAST = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbmk_igemm_desc p) {
-  static_assert(!PERSIST || DBUF, "persistent tiles are double-buffered");
+// OCC: workgroups meant to share a CU (caps the register budget at 512 / (OCC * waves per SIMD)).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 3) / 4) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
   constexpr int RPP = NT / 8;                   // tile rows staged by one LDS-DMA instruction of the block
@@ -172,8 +170,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   // XCD-aware bijective remap: blocks that share an XCD (same blockIdx % 8) get
   // consecutive tiles, so the column tiles of one row panel hit the same L2.
   const int tiles_n = (p.N + BN - 1) / BN;
-  // number of (virtual) workgroups of the remap: every output tile, also when fewer blocks walk them
-  const int nwg = PERSIST ? tiles_n * ((p.M + BM - 1) / BM) : (int)gridDim.x;
+  const int nwg = (int)gridDim.x;
   int m0, n0;
   auto tile_origin = [&](int orig) __attribute__((always_inline)) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -219,10 +216,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   int chb_s = 0, tap_s = 0;   // uniform path: (tap, channel base) of the K-tile
   // staging state of the tile whose origin is (m0, n0)
   auto tile_setup = [&]() __attribute__((always_inline)) {
-    int tt = t;
-    if (PERSIST) asm volatile("" : "+v"(tt));   // recompute per tile instead of keeping it live across the K loop
-    const int rs = PERSIST ? (tt >> 3) : rsub;
-    const int kk_ = PERSIST ? (((tt & 7) ^ ((rs >> 1) & 7)) * 8) : kk;
+    const int rs = rsub, kk_ = kk;
     // descriptor base: first input row any tap of this tile's first output row can touch
     const int b0 = m0 / ohw;
     const int oy0 = (m0 - b0 * ohw) / p.OW;
@@ -242,12 +236,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
         const int b = m / ohw, r2 = m - b * ohw;
         const int oy = r2 / p.OW, ox = r2 - oy * p.OW;
         const int by = oy * p.stride - p.pad_t, bx = ox * p.stride - p.pad_l;
+        unsigned mx = 0, my = 0;   // taps inside the image along x / y; mask = their outer product
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            if (kh < p.KH && kw < p.KW && (unsigned)(by + kh) < (unsigned)IHe && (unsigned)(bx + kw) < (unsigned)IWe)
-              mask |= 1u << (kh * p.KW + kw);
+        for (int k = 0; k < 3; ++k) {
+          if (k < p.KW && (unsigned)(bx + k) < (unsigned)IWe) mx |= 1u << k;
+          if (k < p.KH && (unsigned)(by + k) < (unsigned)IHe) my |= 1u << k;
+        }
+        mask = ((my & 1) ? mx : 0) | ((my & 2) ? mx << p.KW : 0) | ((my & 4) ? mx << (2 * p.KW) : 0);
         int ry = by, rx = bx;
         if (p.up2) {
           mask |= (unsigned)(by & 1) << 16 | (unsigned)(bx & 1) << 17;
@@ -349,28 +344,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
     const char* pa = buf + rdA;
     const char* pb = buf + rdB;
-    if constexpr (PERSIST) {
-      // one set of A fragments: the second k-step's fragment i replaces the first's right after its
-      // last use (frees 4*MI registers for the tile walk state)
-      bf16x8 fa[MI], fb[2];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
-      fb[0] = *(const bf16x8*)(pb + off0);
-#pragma unroll
-      for (int st = 0; st < 2 * NI; ++st) {
-        const int ks = st / NI, j = st % NI;
-        if (st + 1 < 2 * NI) {
-          const int ks2 = (st + 1) / NI, j2 = (st + 1) % NI;
-          fb[(st + 1) & 1] = *(const bf16x8*)(pb + j2 * 16 * 128 + (ks2 ? off1 : off0));
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[st & 1], fa[i], acc[i][j], 0, 0, 0);
-          if (ks == 0 && j == NI - 1) fa[i] = *(const bf16x8*)(pa + i * 16 * 128 + off1);
-        }
-      }
-      return;
-    }
     bf16x8 fa[2][MI], fb[2];
 #pragma unroll
     for (int i = 0; i < MI; ++i) fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
@@ -393,34 +366,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
   };
 
   const int nkt = (p.K + 63) >> 6;
-  if constexpr (PERSIST) {
-    stage(0, smem);
-    while (true) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
-        compute(smem + (kt & 1) * STAGE);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      // every wave is past the last barrier: both stage buffers are free for the next tile
-      const int cm0 = m0, cn0 = n0;
-      vblock += gridDim.x;
-      const bool more = vblock < nwg;
-      if (more) {
-        tile_origin(vblock);
-        tile_setup();
-        stage(0, smem);
-      }
-      igemm_epilogue<MI, NI>(p, acc, cm0 + wm * WM, cn0 + wn * WN, lane, z);
-      if (!more) return;
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  } else if constexpr (DBUF) {
+  if constexpr (DBUF) {
     // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
     // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
     // wave has finished when it passed the barrier that ended iteration kt-1.
@@ -430,12 +376,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
     __syncthreads();
     DBG_T(2);
     for (int kt = 0; kt < nkt; ++kt) {
-      // ABL != 0: timing-only ablations (1: no loads in the loop, 2: no MFMA work, 3: no loads and
-      // no barrier); results are invalid
-      if (ABL != 1 && ABL != 3 && kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
-      if (ABL != 2) compute(smem + (kt & 1) * STAGE);
+      if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+      compute(smem + (kt & 1) * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ABL != 3) __syncthreads();
+      __syncthreads();
     }
   } else {
     for (int kt = 0; kt < nkt; ++kt) {
@@ -449,169 +393,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_kernel(const lbm
 
   DBG_T(3);
   igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
-  if (ABL == 5) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
+  if (STAMP) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
 }
-
-// ------------------------------------------------------------------------------------------------
-// Deep-prefetch variant: 32-deep K tiles in NSTAGE LDS stages.  NSTAGE-1 tiles of LDS-DMA loads are
-// in flight while one is computed; a counted s_waitcnt vmcnt(N) retires only the oldest tile and a raw
-// s_barrier (no vmcnt(0) drain) publishes it, so the L2 -> LDS path never idles between tiles.
-// LDS rows are 64 bytes (4 slots of 16 B, 4 rows per 256-byte bank row); the slot permutation
-// f(g) = [0,2,3,1][(row >> 2) & 3] makes every 16-lane ds_read_b128 group conflict-free.
-// ------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ int swz32(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_k32_kernel(const lbmk_igemm_desc p) {
-  constexpr int NW = WAVES_M * WAVES_N;
-  constexpr int NT = 64 * NW;
-  constexpr int RPP = NT / 4;                   // rows staged per LDS-DMA instruction of the block
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int AI = BM / RPP, BI = BN / RPP;
-  constexpr int STAGE = (BM + BN) * 64;
-  constexpr int LPT = AI + BI;                  // LDS-DMA loads per thread per tile
-  static_assert(BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile shape");
-  static_assert((NSTAGE - 2) * LPT <= 15, "vmcnt immediates");
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  int wgid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int tile_n = wgid % tiles_n;
-  const int tile_m = wgid / tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.z;
-  const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
-  const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z * p.sw;
-
-  const int slot = t & 3, rsub = t >> 2;
-  const int kk = (slot ^ swz32(rsub)) * 8;
-  const int ohw = p.OH * p.OW;
-  const int IHe = p.up2 ? 2 * p.IH : p.IH;
-  const int IWe = p.up2 ? 2 * p.IW : p.IW;
-
-  int a_by[AI], a_bx[AI], a_boff[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + rsub + RPP * i;
-    if (m < p.M) {
-      const int b = m / ohw, rem = m - b * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_by[i] = oy * p.stride - p.pad_t;
-      a_bx[i] = ox * p.stride - p.pad_l;
-      a_boff[i] = b * p.IH * p.IW;
-    } else {
-      a_by[i] = -(1 << 28);
-      a_bx[i] = 0;
-      a_boff[i] = 0;
-    }
-  }
-  const bf16_t* w_ptr[BI];
-#pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int n = n0 + rsub + RPP * i;
-    w_ptr[i] = n < p.N ? W + (int64_t)n * p.Kp + kk : nullptr;
-  }
-  int ch = kk, tap = 0;
-  while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
-  const int ntaps = p.KH * p.KW;
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int lr = lane & 15, lq = lane >> 4;
-  const int rd_off = (lq ^ swz32(lr)) << 4;
-  const int rdA = (wm * WM + lr) * 64 + rd_off;
-  const int rdB = BM * 64 + (wn * WN + lr) * 64 + rd_off;
-
-  auto stage = [&](int kt, char* buf) {
-    int kh = 0, kw = 0;
-    if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
-    const bool tap_ok = tap < ntaps && ch < p.Cin;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int iy = a_by[i] + kh, ix = a_bx[i] + kw;
-      const bool ok = tap_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
-      if (p.up2) { iy >>= 1; ix >>= 1; }
-      const bf16_t* src = ok
-          ? A + ((int64_t)(a_boff[i] + iy * p.IW + ix) * p.a_cs + p.a_coff + ch)
-          : (const bf16_t*)igemm_zero_page;
-      glds16(src, buf + (wave * 16 + RPP * i) * 64);
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const bf16_t* src = (w_ptr[i] && (kt << 5) + kk < p.K) ? w_ptr[i] + (kt << 5)
-                                                               : (const bf16_t*)igemm_zero_page;
-      glds16(src, buf + BM * 64 + (wave * 16 + RPP * i) * 64);
-    }
-    if (p.k_order) {          // chunk-major: (64-channel chunk, tap, 32-channel half)
-      ch += 32;
-      if ((ch & 63) < 32) {   // finished both halves of this (chunk, tap)
-        ch -= 64;
-        if (++tap == ntaps) { tap = 0; ch += 64; }
-      }
-    } else {
-      ch += 32;
-      while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
-    }
-  };
-
-  auto compute = [&](const char* buf) {
-    const char* pa = buf + rdA;
-    const char* pb = buf + rdB;
-    bf16x8 fa[MI], fb[2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(pa + i * 16 * 64);
-    fb[0] = *(const bf16x8*)pb;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (j + 1 < NI) fb[(j + 1) & 1] = *(const bf16x8*)(pb + (j + 1) * 16 * 64);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j & 1], fa[i], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  const int nkt = (p.K + 31) >> 5;
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nkt) stage(s, smem + s * STAGE);
-  int rd_stage = 0, wr_stage = NSTAGE - 1;
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tiles issued after tile kt and still allowed in flight: min(NSTAGE-2, nkt-1-kt)
-    const int ahead = nkt - 1 - kt;
-    if (ahead >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * LPT>();
-    else if (NSTAGE > 3 && ahead == NSTAGE - 3) wait_vmcnt<(NSTAGE > 3 ? NSTAGE - 3 : 0) * LPT>();
-    else if (NSTAGE > 4 && ahead == NSTAGE - 4) wait_vmcnt<(NSTAGE > 4 ? NSTAGE - 4 : 0) * LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    // stage wr_stage was read by tile kt-1, which every wave finished before this barrier
-    if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1, smem + wr_stage * STAGE);
-    compute(smem + rd_stage * STAGE);
-    rd_stage = rd_stage + 1 == NSTAGE ? 0 : rd_stage + 1;
-    wr_stage = wr_stage + 1 == NSTAGE ? 0 : wr_stage + 1;
-  }
-  igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
-}
-
 
 // ---- host side ------------------------------------------------------------------------------
 namespace {
@@ -620,39 +403,19 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {256, 256},    // 7: 256x256 with 16 waves (64x64 per wave)
                           {512, 128},    // 8: 16 waves, for N = 128 layers
                           {256, 128},    // 9: 16 waves (64x32 per wave)
-                          {256, 256},    // 10: 16 waves, 32-deep K tiles, 4 stages, counted vmcnt
-                          {256, 256},    // 11: same, 5 stages
-                          {256, 256},    // 12: tile 7, persistent workgroups
-                          {512, 128}};   // 13: tile 8, persistent workgroups
+                          {256, 128}};   // 10: 8 waves, single-buffered, two workgroups per CU
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
 
-template <int BM, int BN, int WMs, int WNs, bool DBUF, int ABL = 0>
+template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
   if (fast_path(d))
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL, false, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
   else
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, ABL, false, false>), grid, dim3(64 * WMs * WNs), 0, s, d);
-}
-// one workgroup per CU (16 waves, >= 128 KB of LDS each), walking the output tiles
-template <int BM, int BN, int WMs, int WNs>
-void launch_persist(const lbmk_igemm_desc& d, hipStream_t s) {
-  const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
-  const int nt = tm * tn;
-  dim3 grid((unsigned)(nt < lbmk_num_cus() ? nt : lbmk_num_cus()), 1, (unsigned)d.batch);
-  if (fast_path(d))
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
-  else
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, true, 0, true, false>), grid, dim3(64 * WMs * WNs), 0, s, d);
-}
-template <int BM, int BN, int WMs, int WNs, int NSTAGE>
-void launch_k32(const lbmk_igemm_desc& d, hipStream_t s) {
-  const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
-  hipLaunchKernelGGL((igemm_k32_kernel<BM, BN, WMs, WNs, NSTAGE>), grid, dim3(64 * WMs * WNs), 0, s, d);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, false, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
 
@@ -702,51 +465,45 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
     else {
-      // Cost model over the production tiles: workgroups run in rounds of (CUs x resident blocks per
-      // CU); a round costs resident * bm * bn / rate, padded rows / columns included.  `rate` is the
-      // measured full-occupancy throughput of the tile shape (TFLOP/s, mid-size K): the 16-wave
-      // double-buffered tiles move half the L2->LDS bytes per FLOP of the 128x128 tile.
+      // Cost model over the production tiles.  A tile shape keeps `resident` workgroups on a CU and
+      // then sustains `rate` (measured, TFLOP/s at full occupancy, mid-size K); padded rows / columns
+      // are paid in full.  One-per-CU tiles run in whole rounds of the CU count; co-resident tiles
+      // drain smoothly (a CU with fewer workgroups left runs them faster), so their round count is
+      // fractional, floored at half a round.
       struct Cand { int tile, bm, bn, resident; float rate; };
-      static const Cand cands[] = {{7, 256, 256, 1, 1150.f}, {8, 512, 128, 1, 1050.f}, {9, 256, 128, 1, 880.f},
-                                   {0, 128, 128, 2, 800.f},  {1, 128, 64, 3, 700.f},   {3, 64, 64, 5, 450.f}};
+      static const Cand cands[] = {{7, 256, 256, 1, 1300.f}, {8, 512, 128, 1, 1150.f}, {10, 256, 128, 2, 1170.f},
+                                   {0, 128, 128, 4, 1130.f}, {1, 128, 64, 4, 920.f},   {3, 64, 64, 8, 750.f}};
       const int cus = lbmk_num_cus();
       double best = 1e300;
       tile = 0;
       for (const Cand& c : cands) {
-        const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
-        const long slots = (long)cus * c.resident;
-        const long rounds = (blocks + slots - 1) / slots;
-        const double cost = (double)rounds * c.resident * c.bm * c.bn / c.rate;
+        const double blocks = (double)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
+        const double slots = (double)cus * c.resident;
+        double rounds = blocks / slots;
+        if (c.resident == 1) rounds = (double)(long)((blocks + slots - 1) / slots);
+        else if (rounds < 0.5) rounds = 0.5;
+        const double cost = rounds * c.resident * c.bm * c.bn / c.rate;
         if (cost < best) { best = cost; tile = c.tile; }
       }
     }
   }
-  if (tile == 100) { launch<256, 256, 4, 4, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 102) { launch<256, 256, 4, 4, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 110) { launch<512, 128, 8, 2, true, 1>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 111) { launch<512, 128, 8, 2, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 112) { launch<512, 128, 8, 2, true, 3>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 115) { launch<512, 128, 8, 2, true, 5>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 116) { launch<256, 256, 4, 4, true, 5>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
-  if (tile == 101) { launch<256, 256, 4, 4, true, 2>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 115) { launch<512, 128, 8, 2, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
-    case 0: launch<128, 128, 2, 2, false>(d, s); break;
-    case 1: launch<128, 64, 2, 2, false>(d, s); break;
+    case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;
+    case 1: launch<128, 64, 2, 2, false, false, 4>(d, s); break;
     case 2: launch<256, 16, 4, 1, false>(d, s); break;
     case 3: launch<64, 64, 2, 2, false>(d, s); break;
-    case 4: launch<256, 64, 4, 1, false>(d, s); break;
+    case 4: launch<256, 64, 4, 1, false, false, 4>(d, s); break;
     case 5: launch<256, 256, 2, 4, true>(d, s); break;
     case 6: launch<256, 128, 4, 2, true>(d, s); break;
     case 7: launch<256, 256, 4, 4, true>(d, s); break;
     case 8: launch<512, 128, 8, 2, true>(d, s); break;
     case 9: launch<256, 128, 4, 4, true>(d, s); break;
-    case 10: launch_k32<256, 256, 4, 4, 4>(d, s); break;
-    case 11: launch_k32<256, 256, 4, 4, 5>(d, s); break;
-    case 12: launch_persist<256, 256, 4, 4>(d, s); break;
-    case 13: launch_persist<512, 128, 8, 2>(d, s); break;
+    case 10: launch<256, 128, 4, 2, false, false, 2>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
