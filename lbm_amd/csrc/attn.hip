@@ -17,7 +17,13 @@ constexpr int D = 64;
 constexpr int QB = 128;   // query rows per workgroup
 constexpr int KB = 64;    // keys per tile
 
-__global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The softmax arithmetic, not the MFMA pipe, bounds this kernel (per score: scale-and-shift, exp2, sum,
+// bf16 pack, running max on the vector ALU against 16 MFMA cycles), so the loop keeps vector work
+// minimal: packed f32 math, LDS read offsets hoisted out of the loop, and the rescale of the output
+// accumulator only when some row's running maximum actually moved.  128 registers -> 4 waves per SIMD.
+__global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
     int64_t sk, int64_t svt, int64_t so, float scale_log2e) {
@@ -56,6 +62,13 @@ __global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
   const int slot = t & 7, rsub = t >> 3;
   const int cs = slot ^ ((rsub >> 1) & 7);
   const int rswz = (r >> 1) & 7;
+  // loop-invariant LDS read offsets of this lane's fragments
+  int koff[4], voff[8];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ rswz) << 4);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) voff[c] = r * 128 + 8 * h + ((c ^ rswz) << 4);
+  const f32x2 sc2 = {scale_log2e, scale_log2e};
 
   for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
 #pragma unroll
@@ -79,13 +92,11 @@ __global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
     f32x16 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-      const char* krow = sK + (32 * kt + r) * 128;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(krow + (((2 * ks + h) ^ rswz) << 4));
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+        const bf16x8 kf = *(const bf16x8*)(sK + kt * 32 * 128 + koff[ks]);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : s[kt], 0, 0, 0);
       }
     }
     if (kv0 + KB > Nk) {   // mask the keys past the end (wave-uniform branch)
@@ -105,35 +116,47 @@ __global__ __launch_bounds__(256) void flash_fwd_d64_kernel(
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some row's maximum moved: rescale
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const f32x2 a2 = {alpha, alpha};
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          f32x2 v = {o[i][e], o[i][e + 1]};
+          v *= a2;
+          o[i][e] = v.x;
+          o[i][e + 1] = v.y;
+        }
+      m_run = m_new;
+    }
+    const f32x2 nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.f, 0.f};
     bf16x8 pf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s[kt][e] * scale_log2e - m_new);
-        psum += pv;
-        pf[kt][e >> 3][e & 7] = (__bf16)pv;
+      for (int e = 0; e < 16; e += 2) {
+        f32x2 v = {s[kt][e], s[kt][e + 1]};
+        v = v * sc2 + nm2;
+        const f32x2 pv = {__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)};
+        ps2 += pv;
+        pf[kt][e >> 3][e & 7] = (__bf16)pv.x;
+        pf[kt][e >> 3][(e & 7) + 1] = (__bf16)pv.y;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    l_run += ps2.x + ps2.y;
 
     // ---- O^T += V^T P^T ------------------------------------------------------------------
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
-      const char* vrow = sV + (32 * dt + r) * 128 + 8 * h;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
           const int c1 = 4 * kt + 2 * ss;
-          const uint2 lo = *(const uint2*)(vrow + ((c1 ^ rswz) << 4));
-          const uint2 hi = *(const uint2*)(vrow + (((c1 + 1) ^ rswz) << 4));
+          const uint2 lo = *(const uint2*)(sV + dt * 32 * 128 + voff[c1]);
+          const uint2 hi = *(const uint2*)(sV + dt * 32 * 128 + voff[c1 + 1]);
           const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
           const bf16x8 vf = __builtin_bit_cast(bf16x8, pk);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);

@@ -17,9 +17,12 @@
 
 // Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116) record six 100 MHz
 // wall-clock stamps per workgroup: start, after set-up, first stage landed, K loop done, epilogue
-// issued, stores drained.  lbmk_debug_igemm_times() copies them out.  No stamp executes otherwise.
-__device__ unsigned long long igemm_dbg[65536 * 6];
-#define DBG_T(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// issued, stores drained; slots 6 / 7 hold the shader-clock counter at the start / end of the K loop
+// (in-kernel clock = delta(6..7) / delta(2..3) * 100 MHz).  lbmk_debug_igemm_times() copies them out.
+// No stamp executes otherwise.
+__device__ unsigned long long igemm_dbg[65536 * 8];
+#define DBG_T(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define DBG_C(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     DBG_T(2);
+    DBG_C(6);
     for (int kt = 0; kt < nkt; ++kt) {
       if (kt + 1 < nkt) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
       compute(smem + (kt & 1) * STAGE);
@@ -391,6 +395,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     }
   }
 
+  DBG_C(7);
   DBG_T(3);
   igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
   if (STAMP) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
@@ -420,7 +425,7 @@ void launch(const lbmk_igemm_desc& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int lbmk_debug_igemm_times(unsigned long long* host, int nblocks) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(igemm_dbg), (size_t)nblocks * 6 * 8);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(igemm_dbg), (size_t)nblocks * 8 * 8);
 }
 
 extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
