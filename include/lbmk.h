@@ -62,9 +62,17 @@ typedef struct lbmk_igemm_desc {
   int32_t tile;         /* -1 auto, else index into the tile table (see lbmk_igemm_tiles) */
   int32_t k_order;      /* 0: k = tap*Cin + c;  1 (Cin % 64 == 0): k = (c/64)*KH*KW*64 + tap*64 + c%64,
                            i.e. the 9 taps of one 64-channel chunk are consecutive K tiles (L1 reuse) */
+  float* gn_partial;    /* NULL, or GroupNorm partial sums of the (bf16-rounded) output, written by the
+                           epilogue: [image][group][strip of 64 output rows][sum, sum of squares] f32,
+                           lbmk_igemm_gn_partial_floats() floats; consumed by lbmk_groupnorm_from_partials,
+                           which then skips its own statistics pass over the tensor                   */
+  int32_t gn_groups;    /* groups G of the consuming GroupNorm: N % G == 0, N / G in {4, 8, 16},
+                           OH*OW % 64 == 0, Cin % 64 == 0, bf16 output, no GEGLU                        */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
+/* floats behind gn_partial for a descriptor's shape, or -1 when the shape cannot carry fused statistics */
+int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int gn_groups);
 /* number of tile configurations; cfg i has block tile bm[i] x bn[i] */
 int lbmk_igemm_tiles(int* bm, int* bn, int cap);
 
@@ -80,6 +88,12 @@ int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta
                    float* scratch, int B, int HW, int C, int G, float eps,
                    int silu, void* stream);
 
+/* Same normalisation, with the statistics pass replaced by partial sums a producer already wrote
+ * (lbmk_igemm with gn_partial): partial is [B][G][nslab][2] f32; scratch holds 2*B*G floats. */
+int lbmk_groupnorm_from_partials(const void* x, void* y, const float* gamma, const float* beta,
+                                 const float* partial, int nslab, float* scratch, int B, int HW, int C,
+                                 int G, float eps, int silu, void* stream);
+
 /* LayerNorm over the last dim of [rows][C] bf16 (BasicTransformerBlock norm1/2/3, eps 1e-5). */
 int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta,
                    int rows, int C, float eps, void* stream);
@@ -93,7 +107,7 @@ int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta
  *   k  : bf16 [B][Nk][ldk] likewise
  *   vt : bf16 [B][H*D][ldvt]  (V transposed: row = channel, column = key)
  *   o  : bf16 [B][Nq][ldo]
- * Supported D: 64.
+ * Supported D: 40, 64, 80, 160; keys at or past Nk are masked, ldvt >= Nk rounded up to 8.
  * ---------------------------------------------------------------------- */
 int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         int B, int H, int Nq, int Nk, int D,

@@ -45,6 +45,7 @@ class IgemmDesc(C.Structure):
         ("batch", i32),
         ("sa", i64), ("sw", i64), ("so", i64), ("sr", i64),
         ("tile", i32), ("k_order", i32),
+        ("gn_partial", vp), ("gn_groups", i32),
     ]
 
 
@@ -54,6 +55,8 @@ SIGNATURES = {
     "lbmk_last_error": (C.c_char_p, []),
     "lbmk_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
     "lbmk_igemm_tiles": (i32, [C.POINTER(i32), C.POINTER(i32), i32]),
+    "lbmk_igemm_gn_partial_floats": (i64, [i32, i32, i32, i32, i32, i32]),
+    "lbmk_groupnorm_from_partials": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_groupnorm_scratch_floats": (i64, [i32, i32, i32, i32]),
     "lbmk_groupnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),

@@ -30,7 +30,7 @@ __device__ unsigned long long igemm_dbg[65536 * 8];
 // Loads are batched ahead of the stores on purpose: `out` may alias anything as far as the compiler
 // knows, so a load written after a store waits for it.  The bias of all NI column groups is read once,
 // and the residual / rowvec operands of row group i+1 are in flight while row group i is stored.
-template <int MI, int NI>
+template <int MI, int NI, bool GNS>
 __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (&acc)[MI][NI], int mbase,
                                                int nbase, int lane, int z) {
   const int lr = lane & 15, lq = lane >> 4;
@@ -70,6 +70,9 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 
   if (vec_ok) {
     const bool has_add = res || rowvec;
+    // GroupNorm partial sums of this wave's 64-row strip (bf16-rounded values, as a separate
+    // statistics pass over the stored tensor would read them)
+    constexpr bool gn = GNS && MI == 4;   // separate instantiation: the 8 extra accumulators do not fit the plain kernels' budget
     u16x4 rr[NI], rv[NI];
     auto fetch = [&](int i) {
       const int m = mbase + i * 16 + lr;
@@ -117,6 +120,40 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
           *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
+          if (gn) {   // keep the stored (rounded) value for the statistics pass below
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = bf2f(ov.v[e]);
+          }
+        }
+      }
+    }
+    if (gn && mbase < p.M) {
+      const int cpg = p.N / p.gn_groups;        // 4, 8 or 16 channels: whole groups inside a 16-column tile
+      const int bimg = mbase / ohw;
+      const int strip = (mbase - bimg * ohw) >> 6, nslab = ohw >> 6;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (mbase + i * 16 + lr < p.M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a += acc[i][j][e]; b2 += acc[i][j][e] * acc[i][j][e]; }
+          }
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {   // over the 16 rows held by lanes of equal lq
+          a += __shfl_xor(a, off, 64);
+          b2 += __shfl_xor(b2, off, 64);
+        }
+        if (cpg >= 8) { a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64); }
+        if (cpg == 16) { a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64); }
+        const int col = nbase + j * 16 + lq * 4;
+        const bool writer = lr == 0 && col < p.N && (cpg == 4 || (cpg == 8 && !(lq & 1)) || (cpg == 16 && lq == 0));
+        if (writer) {
+          const int g = col / cpg;
+          float* dst = p.gn_partial + (((int64_t)bimg * p.gn_groups + g) * nslab + strip) * 2;
+          *(float2*)dst = make_float2(a, b2);
         }
       }
     }
@@ -151,7 +188,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // FAST: Cin % 64 == 0 -- every lane of a K-tile is on the same filter tap, so the
 // tap / channel walk is scalar and a load costs three vector ALU instructions.
 // OCC: workgroups meant to share a CU (caps the register budget at 512 / (OCC * waves per SIMD)).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 3) / 4) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
@@ -397,7 +434,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
 
   DBG_C(7);
   DBG_T(3);
-  igemm_epilogue<MI, NI>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
+  igemm_epilogue<MI, NI, GNS>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
   if (STAMP) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
 }
 
@@ -417,7 +454,10 @@ template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int O
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
-  if (fast_path(d))
+  if (d.gn_partial) {   // fused GroupNorm statistics: fast path only (checked by the caller)
+    if constexpr (BM / WMs == 64 && BN / WNs == 64 && !STAMP)
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  } else if (fast_path(d))
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
   else
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, false, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
@@ -426,6 +466,13 @@ void launch(const lbmk_igemm_desc& d, hipStream_t s) {
 
 extern "C" int lbmk_debug_igemm_times(unsigned long long* host, int nblocks) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(igemm_dbg), (size_t)nblocks * 8 * 8);
+}
+
+extern "C" int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int G) {
+  if (M <= 0 || N <= 0 || OH <= 0 || OW <= 0 || G <= 0 || N % G || Cin % 64) return -1;
+  const int cpg = N / G, ohw = OH * OW;
+  if ((cpg != 4 && cpg != 8 && cpg != 16) || ohw % 64 || M % ohw) return -1;
+  return (int64_t)(M / 64) * G * 2;
 }
 
 extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
@@ -465,6 +512,14 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     LBMK_REQUIRE(!d.residual && !d.rowvec && !d.out_f32, "igemm: GEGLU epilogue is bias-only, bf16");
   }
   if ((d.so % 4) || (d.sr % 4)) LBMK_REQUIRE(false, "igemm: so/sr must be multiples of 4");
+  const bool gn = d.gn_partial != nullptr;
+  if (gn) {
+    LBMK_REQUIRE(lbmk_igemm_gn_partial_floats(d.M, d.N, d.Cin, d.OH, d.OW, d.gn_groups) > 0,
+                 "igemm: shape M=%d N=%d Cin=%d %dx%d G=%d cannot carry fused GroupNorm statistics", d.M, d.N, d.Cin, d.OH, d.OW, d.gn_groups);
+    LBMK_REQUIRE(!d.out_f32 && d.act != LBMK_ACT_GEGLU && d.batch == 1 && d.ldo % 4 == 0 && lbmk_aligned(d.gn_partial, 8),
+                 "igemm: fused GroupNorm statistics need a bf16, non-GEGLU, unbatched output");
+    LBMK_REQUIRE((!d.residual || d.ldr % 4 == 0) && (!d.rowvec || d.rowvec_ld % 4 == 0), "igemm: gn statistics need 8-byte aligned rows");
+  }
 
   int tile = d.tile;
   if (tile < 0) {
@@ -482,6 +537,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       double best = 1e300;
       tile = 0;
       for (const Cand& c : cands) {
+        if (gn && (c.tile == 1 || c.tile == 3)) continue;   // statistics strips are 64 rows x 64 columns per wave
         const double blocks = (double)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
         const double slots = (double)cus * c.resident;
         double rounds = blocks / slots;
@@ -496,6 +552,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
+  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10, "igemm: tile %d has no 64x64 wave strips", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
     case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;

@@ -99,21 +99,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                   int BG, int nslab, float inv_count, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BG) return;
+// one workgroup per (image, group): threads stride over the slab partials, wave + LDS reduction
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
+                                                          float* __restrict__ stats, int BG, int nslab,
+                                                          float inv_count, float eps) {
+  __shared__ double red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = blockIdx.x;
   // accumulate the slab partials in double: E[x^2]-E[x]^2 then loses nothing to the merge
   double s = 0.0, ss = 0.0;
-  for (int k = 0; k < nslab; ++k) {
-    s += (double)partial[((int64_t)i * nslab + k) * 2];
-    ss += (double)partial[((int64_t)i * nslab + k) * 2 + 1];
+  const float2* pp = (const float2*)partial + (int64_t)i * nslab;
+  for (int k = t; k < nslab; k += 256) {
+    const float2 v = pp[k];
+    s += (double)v.x;
+    ss += (double)v.y;
   }
-  const double mean = s * inv_count;
-  double var = ss * inv_count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[i * 2] = (float)mean;
-  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    ss += __shfl_xor(ss, off, 64);
+  }
+  if (lane == 0) { red[wave * 2] = s; red[wave * 2 + 1] = ss; }
+  __syncthreads();
+  if (t == 0) {
+    s = red[0] + red[2] + red[4] + red[6];
+    ss = red[1] + red[3] + red[5] + red[7];
+    const double mean = s * inv_count;
+    double var = ss * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <bool SILU>
@@ -244,7 +260,7 @@ extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const 
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, partial, HW, C, G,
                      pl.nch, pl.rpp, pl.rows_per_slab, pl.nslab);
   const int BG = B * G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((BG + 255) / 256), dim3(256), 0, s, partial, stats, BG,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(BG), dim3(256), 0, s, partial, stats, BG,
                      pl.nslab, 1.0f / ((float)HW * (float)(C / G)), eps);
   if (silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
@@ -253,6 +269,28 @@ extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const 
     hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        stats, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
   return lbmk_check_launch("groupnorm");
+}
+
+extern "C" int lbmk_groupnorm_from_partials(const void* x, void* y, const float* gamma, const float* beta,
+                                            const float* partial, int nslab, float* scratch, int B, int HW,
+                                            int C, int G, float eps, int silu, void* stream) {
+  LBMK_REQUIRE(x && y && scratch && partial, "groupnorm_from_partials: null pointer");
+  LBMK_REQUIRE(B > 0 && HW > 0 && B <= 65535 && nslab > 0, "groupnorm_from_partials: B=%d HW=%d nslab=%d", B, HW, nslab);
+  GnPlan pl;
+  LBMK_REQUIRE(gn_plan(B, HW, C, G, &pl), "groupnorm: unsupported C=%d G=%d", C, G);
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16) && lbmk_aligned(partial, 8), "groupnorm: misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int BG = B * G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(BG), dim3(256), 0, s, partial, scratch, BG, nslab,
+                     1.0f / ((float)HW * (float)(C / G)), eps);
+  dim3 grid(pl.nslab, pl.S, B);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       scratch, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
+                       scratch, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
+  return lbmk_check_launch("groupnorm_from_partials");
 }
 
 extern "C" int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta,

@@ -38,6 +38,9 @@ class HipConv2d(nn.Conv2d, _Cached):
     def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, asym_pad=False):
         super().__init__(cin, cout, kernel_size, stride=stride, padding=0 if asym_pad else padding)
         self.asym_pad = asym_pad
+        # groups of the GroupNorm that consumes this layer's output (0: none): the convolution then
+        # reduces the statistics in its epilogue and the norm skips its own pass over the tensor
+        self.gn_groups = 0
 
     def packed(self) -> ops.PackedWeight:
         return self._cached("w", (self.weight, self.bias), lambda: ops.pack_conv_weight(self.weight, self.bias))
@@ -47,9 +50,9 @@ class HipConv2d(nn.Conv2d, _Cached):
         if self.asym_pad:
             out_hw = (x.shape[1] // 2, x.shape[2] // 2)
             return ops.conv2d(x, self.packed(), stride=s, pad=(0, 0), out_hw=out_hw, rowvec=rowvec,
-                              residual=residual, act=act)
+                              residual=residual, act=act, gn_groups=self.gn_groups)
         return ops.conv2d(x, self.packed(), stride=s, pad=(self.padding[0], self.padding[1]), up2=up2,
-                          rowvec=rowvec, residual=residual, act=act)
+                          rowvec=rowvec, residual=residual, act=act, gn_groups=self.gn_groups)
 
 
 class HipLinear(nn.Linear, _Cached):

@@ -197,6 +197,11 @@ class AutoencoderKL(nn.Module):
         self.decoder = Decoder(latent_channels, out_channels, block_out_channels, layers_per_block, norm_num_groups)
         self.quant_conv = HipConv2d(2 * latent_channels, 2 * latent_channels, 1, padding=0)
         self.post_quant_conv = HipConv2d(latent_channels, latent_channels, 1, padding=0)
+        # every 3x3 convolution of the encoder / decoder body feeds a GroupNorm (norm2, the next block's
+        # norm1, the attention's group_norm or conv_norm_out): let it reduce that norm's statistics
+        for name, m in self.named_modules():
+            if isinstance(m, HipConv2d) and not name.endswith(("conv_shortcut", "conv_out", "quant_conv")):
+                m.gn_groups = norm_num_groups
 
     @property
     def downsampling_factor(self) -> int:

@@ -150,10 +150,12 @@ def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None):
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up2: bool = False,
            out_hw=None, rowvec: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, cin_off: int = 0, tile: int = -1) -> torch.Tensor:
+           act: int = ACT_NONE, cin_off: int = 0, tile: int = -1, gn_groups: int = 0) -> torch.Tensor:
     """x: bf16 [B, IH, IW, Cs] channels-last; reads channels [cin_off, cin_off + pw.Cin).
     pad = (top, left); the bottom/right extent follows from out_hw (default: 'same' rule
-    (I + 2*pad - K)//stride + 1 with symmetric padding)."""
+    (I + 2*pad - K)//stride + 1 with symmetric padding).
+    gn_groups > 0: the epilogue also writes GroupNorm partial sums for a consumer with that many groups
+    (when the shape allows); they ride on the returned tensor and `groupnorm` picks them up."""
     _need_gpu(x, pw.w)
     assert x.dtype == bf16 and x.dim() == 4 and x.is_contiguous()
     B, IH, IW, Cs = x.shape
@@ -189,8 +191,21 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
     d.k_order = pw.k_order
+    partial = _attach_gn_partial(d, out, gn_groups) if gn_groups and n_out == pw.N else None
     _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
+    if partial is not None:
+        out._lbmk_gn_partial = partial
     return out
+
+
+def _attach_gn_partial(d: IgemmDesc, out: torch.Tensor, groups: int):
+    """Allocate the statistics buffer of a producer launch; None when the shape is not eligible."""
+    nfl = lib.lbmk_igemm_gn_partial_floats(d.M, d.N, d.Cin, d.OH, d.OW, groups)
+    if nfl <= 0 or d.ldo != d.N:
+        return None
+    buf = torch.empty(nfl, dtype=torch.float32, device=out.device)
+    d.gn_partial, d.gn_groups = buf.data_ptr(), groups
+    return (buf, groups, (d.OH * d.OW) // 64)
 
 
 def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor] = None,
@@ -290,6 +305,16 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     assert x.dtype == bf16 and x.is_contiguous()
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    fused = getattr(x, "_lbmk_gn_partial", None)
+    if fused is not None and fused[1] == groups and fused[0].numel() == B * groups * fused[2] * 2:
+        # the producing convolution already reduced this tensor: finalize + apply only
+        pbuf, _, nslab = fused
+        stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.lbmk_groupnorm_from_partials(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), pbuf.data_ptr(),
+                                               nslab, stats.data_ptr(), B, HW, Cc, groups, eps, 1 if silu else 0,
+                                               _stream()), "lbmk_groupnorm_from_partials")
+        return y
     nfl = lib.lbmk_groupnorm_scratch_floats(B, HW, Cc, groups)
     if nfl < 0:
         raise _C.LbmkError(f"groupnorm: unsupported shape B={B} HW={HW} C={Cc} G={groups}")

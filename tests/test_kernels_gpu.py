@@ -384,3 +384,34 @@ def test_conv3x3_many_tiles_two_images(ops, cuda, gen, tile):
     ref = _conv_ref(x, w, b, 1, 1) + res.float()
     assert rel_l2(y, ref) < 4e-3
     assert (y.float().cpu() - ref).abs().max() < 0.1
+
+
+@pytest.mark.parametrize("cout,tile", [(128, -1), (128, 8), (128, 10), (256, 7), (512, 7), (256, 0)])
+def test_conv_fused_groupnorm_stats(ops, cuda, gen, cout, tile):
+    """the convolution's epilogue reduces the statistics of the GroupNorm that follows: same result as
+    the stand-alone statistics pass, and equal to torch's group_norm on the stored tensor"""
+    B, H, W, cin, G = 3, 24, 32, 64, 32
+    x = randbf(gen, B, H, W, cin)
+    w = randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5)
+    b = randbf(gen, cout)
+    res = randbf(gen, B, H, W, cout)
+    gam, bet = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+    pw = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
+    y = ops.conv2d(x.to(cuda), pw, residual=res.to(cuda), tile=tile, gn_groups=G)
+    assert getattr(y, "_lbmk_gn_partial", None) is not None
+    y_plain = ops.conv2d(x.to(cuda), pw, residual=res.to(cuda), tile=tile)
+    assert torch.equal(y, y_plain)
+    n_fused = ops.groupnorm(y, gam.to(cuda), bet.to(cuda), G, 1e-6, True)
+    n_plain = ops.groupnorm(y_plain, gam.to(cuda), bet.to(cuda), G, 1e-6, True)
+    ref = F.silu(F.group_norm(y.float().cpu().permute(0, 3, 1, 2), G, gam, bet, 1e-6)).permute(0, 2, 3, 1)
+    assert rel_l2(n_fused, ref) < 4e-3
+    assert (n_fused.float() - n_plain.float()).abs().max() < 0.04   # one bf16 ulp at |x| <= 4
+
+
+def test_conv_fused_groupnorm_stats_ineligible(ops, cuda, gen):
+    """shapes the epilogue cannot reduce (10 channels per group) silently use the separate pass"""
+    x = randbf(gen, 2, 16, 16, 64)
+    w = randbf(gen, 320, 64, 3, 3, scale=(9 * 64) ** -0.5)
+    pw = ops.pack_conv_weight(w.to(cuda), None)
+    y = ops.conv2d(x.to(cuda), pw, gn_groups=32)
+    assert getattr(y, "_lbmk_gn_partial", None) is None
