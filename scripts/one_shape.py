@@ -10,6 +10,8 @@ if kind == "conv512":
     B, H, cin, cout = 16, 128, 512, 512
 elif kind == "conv128":
     B, H, cin, cout = 4, 1024, 128, 128
+elif kind == "conv512big":      # the dominant benchmark shape: 1.07 GB in, 1.07 GB out (past the 256 MB cache)
+    B, H, cin, cout = 16, 256, 512, 512
 x = torch.randn(B, H, H, cin, device=dev, generator=g).to(BF)
 w = torch.randn(cout, cin, 3, 3, device=dev, generator=g).to(BF) * (9 * cin) ** -0.5
 pw = ops.pack_conv_weight(w, torch.zeros(cout, device=dev))
