@@ -185,6 +185,32 @@ int lbmk_tile_accumulate(const void* tile, float* acc, float* wsum,
 int lbmk_tile_finalize(const float* acc, const float* wsum, void* out,
                        int B, int C, int H, int W, int out_dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Backward (training) path: the reference back-propagates through diffusers' UNet with torch
+ * autograd (Lightning's training_step, examples/training/train_base.py:55-70 around
+ * LBMModel.forward, src/lbm/models/lbm/lbm_model.py:96-184).  Here every gradient GEMM is an
+ * lbmk_igemm launch on re-laid-out operands produced by the kernels below:
+ *   dX = dY . W          igemm with the transposed (conv: flipped) packed weight
+ *   dW = dY^T . col(X)   igemm over dY^T [N][M] and col(X)^T [K][M] (reduction over rows)
+ * ---------------------------------------------------------------------- */
+/* out[c][r] = in[r][c], bf16; R and C multiples of 8 */
+int lbmk_transpose(const void* in, void* out, int64_t R, int C, int64_t ld_in, int64_t ld_out, void* stream);
+/* transposed im2col of a convolution input (same geometry fields as lbmk_igemm_desc):
+ * out[(kh*KW+kw)*Cin + c][p] = x[pixel read by tap (kh,kw) of output pixel p][c], 0 outside the image;
+ * out is [KH*KW*Cin][ld_out] bf16, ld_out >= B*OH*OW */
+int lbmk_im2col_t(const void* x, void* out, int B, int IH, int IW, int OH, int OW, int KH, int KW,
+                  int stride, int pad_t, int pad_l, int up2, int Cin, int a_cs, int a_coff,
+                  int64_t ld_out, void* stream);
+/* input gradient of a strided / upsampled convolution from dcol = dY . Wpacked ([B*OH*OW][ld_col] bf16):
+ * dx[q][c] = sum over taps and over output pixels p whose tap reads q of dcol[p][tap*Cin + c]; dx NHWC bf16 */
+int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, int OH, int OW, int KH, int KW,
+                int stride, int pad_t, int pad_l, int up2, int Cin, int64_t ld_col, int dx_cs, void* stream);
+/* out[g][n] = sum of x[m][n] over the rows_per_group consecutive rows of group g (bias gradient: one group;
+ * time-embedding gradient: one group per image).  x bf16 [rows][ld]; out bf16 (0) / f32 (1) [rows/rows_per_group][N] */
+int64_t lbmk_colsum_scratch_floats(int64_t rows, int64_t rows_per_group, int N);
+int lbmk_colsum(const void* x, void* out, float* scratch, int64_t rows, int64_t rows_per_group, int N,
+                int64_t ld, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,11 @@ SIGNATURES = {
     "lbmk_tile_accumulate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                    i32, i32, vp]),
     "lbmk_tile_finalize": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "lbmk_transpose": (i32, [vp, vp, i64, i32, i64, i64, vp]),
+    "lbmk_im2col_t": (i32, [vp, vp] + [i32] * 14 + [i64, vp]),
+    "lbmk_col2im": (i32, [vp, vp] + [i32] * 12 + [i64, i32, vp]),
+    "lbmk_colsum_scratch_floats": (i64, [i64, i64, i32]),
+    "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -45,8 +45,32 @@ class HipConv2d(nn.Conv2d, _Cached):
     def packed(self) -> ops.PackedWeight:
         return self._cached("w", (self.weight, self.bias), lambda: ops.pack_conv_weight(self.weight, self.bias))
 
+    def packed_dgrad(self) -> ops.PackedWeight:
+        """input-gradient filter of a stride-1 convolution: in/out channels swapped, taps flipped"""
+        return self._cached("d", (self.weight,),
+                            lambda: ops.pack_conv_weight(self.weight.permute(1, 0, 2, 3).flip(2, 3).contiguous(), None))
+
+    def packed_col_t(self) -> ops.PackedWeight:
+        """[KH*KW*Cin_p, Cout_p] matrix (tap-major rows): dcol = dY . W for the col2im input gradient"""
+        def build():
+            n, cin, kh, kw = self.weight.shape
+            cin_p, n_p = ops.ceil_to(cin, 8), ops.ceil_to(n, 8)
+            wk = torch.zeros(n_p, kh * kw, cin_p, dtype=torch.bfloat16, device=self.weight.device)
+            wk[:n, :, :cin] = self.weight.detach().permute(0, 2, 3, 1).reshape(n, kh * kw, cin).to(torch.bfloat16)
+            return ops.pack_linear_weight(wk.reshape(n_p, kh * kw * cin_p).t().contiguous(), None)
+        return self._cached("c", (self.weight,), build)
+
     def forward(self, x, *, up2=False, rowvec=None, residual=None, act=ops.ACT_NONE):
         s = self.stride[0]
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            if act != ops.ACT_NONE:
+                raise NotImplementedError("fused activations are inference-only; apply the activation as its own op when training")
+            from ..autograd import Conv2dFn
+            if self.asym_pad:
+                return Conv2dFn.apply(x, self.weight, self.bias, residual, rowvec, self, s, (0, 0), False,
+                                      (x.shape[1] // 2, x.shape[2] // 2))
+            return Conv2dFn.apply(x, self.weight, self.bias, residual, rowvec, self, s,
+                                  (self.padding[0], self.padding[1]), up2, None)
         if self.asym_pad:
             out_hw = (x.shape[1] // 2, x.shape[2] // 2)
             return ops.conv2d(x, self.packed(), stride=s, pad=(0, 0), out_hw=out_hw, rowvec=rowvec,
@@ -62,7 +86,16 @@ class HipLinear(nn.Linear, _Cached):
     def packed_geglu(self) -> ops.PackedWeight:
         return self._cached("g", (self.weight, self.bias), lambda: ops.pack_geglu_weight(self.weight, self.bias))
 
+    def packed_t(self) -> ops.PackedWeight:
+        """W^T as a packed [K, N] layer: dX = dY . W is the forward GEMM on it"""
+        return self._cached("t", (self.weight,), lambda: ops.pack_linear_weight(self.weight.t().contiguous(), None))
+
     def forward(self, x, *, residual=None, rowvec=None, rows_per_image=0, act=ops.ACT_NONE, geglu=False, out=None):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            if act != ops.ACT_NONE or geglu or out is not None:
+                raise NotImplementedError("fused activations / preallocated outputs are inference-only")
+            from ..autograd import LinearFn
+            return LinearFn.apply(x, self.weight, self.bias, residual, rowvec, self, rows_per_image)
         pw = self.packed_geglu() if geglu else self.packed()
         return ops.linear(x, pw, residual=residual, rowvec=rowvec, rows_per_image=rows_per_image, act=act, out=out)
 

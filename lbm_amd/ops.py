@@ -516,3 +516,90 @@ def tile_finalize(acc, wsum, out_dtype=torch.float32):
     check(lib.lbmk_tile_finalize(acc.data_ptr(), wsum.data_ptr(), out.data_ptr(), B, Cc, H, W, _dt(out), _stream()),
           "tile_finalize")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# backward (training) path: operand re-layout and reductions; the GEMMs are lbmk_igemm launches
+# --------------------------------------------------------------------------------------
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """bf16 [R, C] (row stride >= C) -> contiguous [C, R]; R and C multiples of 8."""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    out = torch.empty(Cc, R, dtype=bf16, device=x.device)
+    check(lib.lbmk_transpose(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), R, _stream()), "lbmk_transpose")
+    return out
+
+
+def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torch.float32) -> torch.Tensor:
+    """x: bf16 [rows, N] -> [rows / rows_per_group, N] sums over each group of consecutive rows."""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
+    rows, N = x.shape
+    rpg = rows if rows_per_group is None else rows_per_group
+    nfl = lib.lbmk_colsum_scratch_floats(rows, rpg, N)
+    if nfl <= 0:
+        raise _C.LbmkError(f"colsum: rows={rows} rows_per_group={rpg} N={N}")
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    out = torch.empty(rows // rpg, N, dtype=out_dtype, device=x.device)
+    check(lib.lbmk_colsum(x.data_ptr(), out.data_ptr(), scratch.data_ptr(), rows, rpg, N, x.stride(0), _dt(out),
+                          _stream()), "lbmk_colsum")
+    return out
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """out[n][k] = sum_m a[m][n] * b[m][k]  (weight gradient: a = dY [M, N], b = X or col(X) given
+    row-major [M, K], or already transposed via ``b_t`` = [K, M]).  The reduction runs over the rows, so
+    both operands are transposed first and the row range is split across workgroups (split-K)."""
+    return gemm_tn_t(transpose(_pad_rows8(a)), transpose(_pad_rows8(b)), out_dtype)
+
+
+def _pad_rows8(x: torch.Tensor) -> torch.Tensor:
+    r = x.shape[0]
+    if r % 8 == 0:
+        return x
+    return torch.nn.functional.pad(x, (0, 0, 0, 8 - r % 8))
+
+
+def gemm_tn_t(a_t: torch.Tensor, b_t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """out[n][k] = sum_m a_t[n][m] * b_t[k][m]; a_t bf16 [N, M], b_t bf16 [K, M] contiguous, M % 8 == 0."""
+    _need_gpu(a_t, b_t)
+    N, M = a_t.shape
+    K = b_t.shape[0]
+    assert b_t.shape[1] == M and M % 8 == 0 and a_t.is_contiguous() and b_t.is_contiguous()
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    S = max(1, min(256 // tiles, M // 1024))
+    while S > 1 and (M % S or (M // S) % 8):
+        S -= 1
+    if S == 1:
+        return gemm_nt(a_t, b_t, out_dtype=out_dtype)
+    ms = M // S
+    # chunk s = columns [s*ms, (s+1)*ms) of both operands: batch stride ms, row stride M
+    a3 = a_t.as_strided((S, N, ms), (ms, M, 1))
+    b3 = b_t.as_strided((S, K, ms), (ms, M, 1))
+    part = gemm_nt(a3, b3, out_dtype=torch.float32)
+    return part.sum(0).to(out_dtype)
+
+
+def im2col_t(x: torch.Tensor, cin: int, KH: int, KW: int, stride: int, pad, up2: bool, out_hw, cin_off: int = 0):
+    """Transposed im2col of the NHWC input of a convolution: bf16 [KH*KW*cin, B*OH*OW]."""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.dim() == 4 and x.is_contiguous()
+    B, IH, IW, Cs = x.shape
+    OH, OW = out_hw
+    M = B * OH * OW
+    out = torch.empty(KH * KW * cin, M, dtype=bf16, device=x.device)
+    check(lib.lbmk_im2col_t(x.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, KH, KW, stride, pad[0], pad[1],
+                            1 if up2 else 0, cin, Cs, cin_off, M, _stream()), "lbmk_im2col_t")
+    return out
+
+
+def col2im(dcol: torch.Tensor, B: int, IH: int, IW: int, OH: int, OW: int, cin: int, KH: int, KW: int, stride: int,
+           pad, up2: bool) -> torch.Tensor:
+    """dcol: bf16 [B*OH*OW, >= KH*KW*cin] -> input gradient NHWC bf16 [B, IH, IW, cin]."""
+    _need_gpu(dcol)
+    assert dcol.dtype == bf16 and dcol.dim() == 2 and dcol.stride(1) == 1
+    dx = torch.empty(B, IH, IW, cin, dtype=bf16, device=dcol.device)
+    check(lib.lbmk_col2im(dcol.data_ptr(), dx.data_ptr(), B, IH, IW, OH, OW, KH, KW, stride, pad[0], pad[1],
+                          1 if up2 else 0, cin, dcol.stride(0), cin, _stream()), "lbmk_col2im")
+    return dx

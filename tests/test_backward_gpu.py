@@ -1,0 +1,114 @@
+"""Backward (training) kernels against torch autograd in fp32 on the CPU, same seeded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def gen():
+    return torch.Generator().manual_seed(1234)
+
+
+def randbf(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(BF)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def test_transpose_colsum(cuda, gen):
+    from lbm_amd import ops
+    x = randbf(gen, 136, 72)
+    assert torch.equal(ops.transpose(x.to(cuda)).cpu(), x.t().contiguous())
+    s = ops.colsum(x.to(cuda))
+    assert rel_l2(s, x.float().sum(0, keepdim=True)) < 1e-5
+    s4 = ops.colsum(x.to(cuda), 34, out_dtype=BF)
+    assert rel_l2(s4, x.float().reshape(4, 34, 72).sum(1)) < 4e-3
+
+
+@pytest.mark.parametrize("M,K,N", [(300 * 8, 320, 640), (16, 1280, 320), (4096, 64, 72)])
+def test_linear_backward(cuda, gen, M, K, N):
+    from lbm_amd.models.layers import HipLinear
+    lin = HipLinear(K, N).to(BF)
+    with torch.no_grad():
+        lin.weight.copy_(randbf(gen, N, K, scale=K ** -0.5))
+        lin.bias.copy_(randbf(gen, N))
+    x = randbf(gen, M, K)
+    res = randbf(gen, M, N)
+    dy = randbf(gen, M, N)
+    # reference: fp32 autograd on the same bf16-rounded values
+    xr, wr, br, rr = (t.float().requires_grad_() for t in (x, lin.weight.detach(), lin.bias.detach(), res))
+    (F.linear(xr, wr, br) + rr).backward(dy.float())
+    lin = lin.to(cuda)
+    xg, rg = x.to(cuda).requires_grad_(), res.to(cuda).requires_grad_()
+    y = lin(xg, residual=rg)
+    y.backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 5e-3
+    assert rel_l2(lin.weight.grad, wr.grad) < 5e-3
+    assert rel_l2(lin.bias.grad, br.grad) < 5e-3
+    assert torch.equal(rg.grad.cpu(), dy)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,stride,up2,asym", [(64, 128, 16, 24, 1, False, False), (320, 320, 16, 16, 2, False, False),
+                                                          (64, 64, 8, 8, 1, True, False), (128, 128, 16, 16, 2, False, True),
+                                                          (8, 320, 16, 16, 1, False, False), (320, 8, 16, 16, 1, False, False)])
+def test_conv_backward(cuda, gen, cin, cout, H, W, stride, up2, asym):
+    from lbm_amd.models.layers import HipConv2d
+    B = 2
+    conv = HipConv2d(cin, cout, 3, stride=stride, padding=0 if asym else 1, asym_pad=asym).to(BF)
+    with torch.no_grad():
+        conv.weight.copy_(randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5))
+        conv.bias.copy_(randbf(gen, cout))
+    x = randbf(gen, B, H, W, cin)
+    # reference
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    wr, br = conv.weight.detach().float().requires_grad_(), conv.bias.detach().float().requires_grad_()
+    xi = F.interpolate(xr, scale_factor=2.0, mode="nearest") if up2 else xr
+    if asym:
+        yr = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wr, br, stride=2)
+    else:
+        yr = F.conv2d(xi, wr, br, stride=stride, padding=1)
+    dy = randbf(gen, *yr.permute(0, 2, 3, 1).shape)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    conv = conv.to(cuda)
+    xg = x.to(cuda).requires_grad_()
+    y = conv(xg, up2=up2)
+    assert y.shape[:3] == dy.shape[:3]
+    dyp = F.pad(dy, (0, y.shape[-1] - dy.shape[-1])).to(cuda)     # thin outputs carry zero channels up to 8
+    assert rel_l2(y[..., :cout], yr.permute(0, 2, 3, 1)) < 5e-3
+    y.backward(dyp)
+    assert rel_l2(xg.grad, xr.grad.permute(0, 2, 3, 1)) < 6e-3
+    assert rel_l2(conv.weight.grad, wr.grad) < 6e-3
+    assert rel_l2(conv.bias.grad, br.grad) < 6e-3
+
+
+def test_conv_backward_rowvec_residual(cuda, gen):
+    from lbm_amd.models.layers import HipConv2d
+    B, H, W, cin, cout = 3, 8, 8, 64, 128
+    conv = HipConv2d(cin, cout, 3, padding=1).to(BF)
+    with torch.no_grad():
+        conv.weight.copy_(randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5))
+        conv.bias.copy_(randbf(gen, cout))
+    x, rv, res = randbf(gen, B, H, W, cin), randbf(gen, B, cout), randbf(gen, B, H, W, cout)
+    dy = randbf(gen, B, H, W, cout)
+    xr, rvr, rr = x.float().requires_grad_(), rv.float().requires_grad_(), res.float().requires_grad_()
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), conv.weight.detach().float(), conv.bias.detach().float(), padding=1).permute(0, 2, 3, 1)
+    (yr + rvr[:, None, None, :] + rr).backward(dy.float())
+    conv = conv.to(cuda)
+    xg, rvg, rg = x.to(cuda).requires_grad_(), rv.to(cuda).requires_grad_(), res.to(cuda).requires_grad_()
+    conv(xg, rowvec=rvg, residual=rg).backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 6e-3
+    assert rel_l2(rvg.grad, rvr.grad) < 6e-3
+    assert torch.equal(rg.grad.cpu(), dy)
