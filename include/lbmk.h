@@ -193,8 +193,9 @@ int lbmk_tile_finalize(const float* acc, const float* wsum, void* out,
  *   dX = dY . W          igemm with the transposed (conv: flipped) packed weight
  *   dW = dY^T . col(X)   igemm over dY^T [N][M] and col(X)^T [K][M] (reduction over rows)
  * ---------------------------------------------------------------------- */
-/* out[c][r] = in[r][c], bf16; R and C multiples of 8 */
-int lbmk_transpose(const void* in, void* out, int64_t R, int C, int64_t ld_in, int64_t ld_out, void* stream);
+/* out[z][c][r] = in[z][r][c], bf16; R and C multiples of 8; batch matrices s_in / s_out elements apart */
+int lbmk_transpose(const void* in, void* out, int64_t R, int C, int64_t ld_in, int64_t ld_out,
+                   int batch, int64_t s_in, int64_t s_out, void* stream);
 /* transposed im2col of a convolution input (same geometry fields as lbmk_igemm_desc):
  * out[(kh*KW+kw)*Cin + c][p] = x[pixel read by tap (kh,kw) of output pixel p][c], 0 outside the image;
  * out is [KH*KW*Cin][ld_out] bf16, ld_out >= B*OH*OW */
@@ -210,6 +211,28 @@ int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, int OH, int O
 int64_t lbmk_colsum_scratch_floats(int64_t rows, int64_t rows_per_group, int N);
 int lbmk_colsum(const void* x, void* out, float* scratch, int64_t rows, int64_t rows_per_group, int N,
                 int64_t ld, int out_dtype, void* stream);
+
+/* GroupNorm(+SiLU) backward (torch autograd of nn.GroupNorm + SiLU in diffusers' ResnetBlock2D).
+ * stats: [B][G][mean, rstd] f32 as left by the forward pass; dgamma / dbeta f32 [C] (may be NULL). */
+int64_t lbmk_groupnorm_bwd_scratch_floats(int B, int HW, int C, int G);
+int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
+                       const float* beta, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
+                       int G, int silu, void* stream);
+/* LayerNorm backward; dgamma_dbeta f32 [2][C] (row 0 dgamma, row 1 dbeta), may be NULL; C <= 2048 */
+int64_t lbmk_layernorm_bwd_scratch_floats(int rows, int C);
+int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma_dbeta,
+                       float* scratch, int rows, int C, float eps, void* stream);
+/* dx = dy * silu'(x), bf16, n % 8 == 0 */
+int lbmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+/* GEGLU (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)): h bf16 [rows][2F] */
+int lbmk_geglu_fwd(const void* h, void* y, int64_t rows, int F, void* stream);
+int lbmk_geglu_bwd(const void* h, const void* dy, void* dh, int64_t rows, int F, void* stream);
+/* softmax backward on rows: dS = scale * P * (dP - rowsum(dP * P)); P bf16, dP f32, dS bf16 */
+int lbmk_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, float scale, void* stream);
+/* gradient of lbmk_latent_loss w.r.t. pred given gout f32 [B] (lbm_model.py:186-195) */
+int lbmk_latent_loss_bwd(const void* pred, const void* z_src, const void* z, const uint8_t* mask,
+                         const float* gout, void* dpred, int B, int64_t per_sample, int l1, int pred_dtype,
+                         int z_dtype, void* stream);
 
 #ifdef __cplusplus
 }

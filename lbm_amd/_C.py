@@ -77,11 +77,20 @@ SIGNATURES = {
     "lbmk_tile_accumulate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                    i32, i32, vp]),
     "lbmk_tile_finalize": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "lbmk_transpose": (i32, [vp, vp, i64, i32, i64, i64, vp]),
+    "lbmk_transpose": (i32, [vp, vp, i64, i32, i64, i64, i32, i64, i64, vp]),
     "lbmk_im2col_t": (i32, [vp, vp] + [i32] * 14 + [i64, vp]),
     "lbmk_col2im": (i32, [vp, vp] + [i32] * 12 + [i64, i32, vp]),
     "lbmk_colsum_scratch_floats": (i64, [i64, i64, i32]),
     "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
+    "lbmk_groupnorm_bwd_scratch_floats": (i64, [i32, i32, i32, i32]),
+    "lbmk_groupnorm_bwd": (i32, [vp] * 9 + [i32] * 5 + [vp]),
+    "lbmk_layernorm_bwd_scratch_floats": (i64, [i32, i32]),
+    "lbmk_layernorm_bwd": (i32, [vp] * 6 + [i32, i32, f32, vp]),
+    "lbmk_silu_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "lbmk_geglu_fwd": (i32, [vp, vp, i64, i32, vp]),
+    "lbmk_geglu_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "lbmk_softmax_bwd_rows": (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    "lbmk_latent_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

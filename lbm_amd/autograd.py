@@ -94,3 +94,149 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.has_rv and ctx.needs_input_grad[4]:
             drv = ops.colsum(dy2, OH * OW, out_dtype=bf16)
         return dx, dw, db, dres, drv, None, None, None, None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    """GroupNorm with optional fused SiLU; gamma / beta are the module's parameters (any float dtype)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, silu):
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, stats = ops.groupnorm_train(x, g32, b32, groups, eps, silu)
+        ctx.save_for_backward(x, stats, g32, b32)
+        ctx.cfg = (groups, silu, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, g32, b32 = ctx.saved_tensors
+        groups, silu, wdt = ctx.cfg
+        dx, dg, db = ops.groupnorm_bwd(x, dy.contiguous(), stats, g32, b32, groups, silu)
+        return dx, dg.to(wdt), db.to(wdt), None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = ops.layernorm(x, g32, b32, eps)
+        ctx.save_for_backward(x, g32)
+        ctx.cfg = (eps, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32 = ctx.saved_tensors
+        eps, wdt = ctx.cfg
+        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), g32, eps)
+        return dx, dg.to(wdt), db.to(wdt), None
+
+
+class SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.silu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.silu_bwd(x, dy.contiguous())
+
+
+class GegluFn(torch.autograd.Function):
+    """h = [value | gate] -> value * gelu(gate) (diffusers GEGLU)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return ops.geglu_fwd(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return ops.geglu_bwd(h, dy.contiguous())
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v per head, heads interleaved along the channel axis ([B, N, H*D]).
+    Training path: scores are materialised one head at a time (batched over images) with the implicit-GEMM
+    kernel, probabilities are recomputed in the backward pass; q, k, v are all that is saved."""
+
+    @staticmethod
+    def _probs(q, k, h, D, scale):
+        s = ops.gemm_nt(q[..., h * D:(h + 1) * D], k[..., h * D:(h + 1) * D], out_dtype=torch.float32, alpha=scale)
+        return ops.softmax_rows(s)                                   # [B, Nq, Nk] bf16
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, dim_head, scale):
+        B, Nq, C = q.shape
+        if k.shape[1] % 8 or Nq % 8:
+            raise NotImplementedError("training attention needs token counts that are multiples of 8")
+        o = torch.empty(B, Nq, C, dtype=bf16, device=q.device)
+        vt = ops.transpose(v)                                        # [B, C, Nk]
+        for h in range(heads):
+            p = AttentionFn._probs(q, k, h, dim_head, scale)
+            ops.gemm_nt(p, vt[:, h * dim_head:(h + 1) * dim_head, :], out=o[..., h * dim_head:(h + 1) * dim_head])
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (heads, dim_head, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        heads, D, scale = ctx.cfg
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        qt, kt, dot = ops.transpose(q), ops.transpose(k), ops.transpose(do)      # [B, C, N]
+        for h in range(heads):
+            sl = slice(h * D, (h + 1) * D)
+            p = AttentionFn._probs(q, k, h, D, scale)                            # [B, Nq, Nk]
+            pt = ops.transpose(p)                                                # [B, Nk, Nq]
+            ops.gemm_nt(pt, dot[:, sl, :], out=dv[..., sl])                      # dV = P^T dO
+            dp = ops.gemm_nt(do[..., sl], v[..., sl], out_dtype=torch.float32)   # dP = dO V^T
+            ds = ops.softmax_bwd_rows(p, dp, scale)                              # [B, Nq, Nk]
+            ops.gemm_nt(ds, kt[:, sl, :], out=dq[..., sl])                       # dQ = dS K
+            ops.gemm_nt(ops.transpose(ds), qt[:, sl, :], out=dk[..., sl])        # dK = dS^T Q
+        return dq, dk, dv, None, None, None
+
+
+class NchwToNhwcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.cfg = (x.shape[1], x.dtype)
+        return ops.nchw_to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        C, dt = ctx.cfg
+        return ops.nhwc_to_nchw(dy.contiguous(), C, out_dtype=dt)
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C, out_dtype):
+        ctx.cp = x.shape[-1]
+        return ops.nhwc_to_nchw(x, C, out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ops.nchw_to_nhwc(dy.contiguous())           # channels zero-padded to a multiple of 8
+        if dx.shape[-1] != ctx.cp:
+            dx = torch.nn.functional.pad(dx, (0, ctx.cp - dx.shape[-1]))
+        return dx, None, None
+
+
+class LatentLossFn(torch.autograd.Function):
+    """per-sample mean of ((pred - (z_src - z)) * mask)^2 or |.| (src/lbm/models/lbm/lbm_model.py:186-195)."""
+
+    @staticmethod
+    def forward(ctx, pred, z_src, z, mask, l1):
+        ctx.save_for_backward(pred, z_src, z, mask if mask is not None else torch.empty(0))
+        ctx.l1, ctx.has_mask = l1, mask is not None
+        return ops.latent_loss(pred.contiguous(), z_src.contiguous(), z.contiguous(), mask, l1=l1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, z_src, z, mask = ctx.saved_tensors
+        return ops.latent_loss_bwd(pred, z_src, z, mask if ctx.has_mask else None, gout, ctx.l1), None, None, None, None

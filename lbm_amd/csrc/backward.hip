@@ -11,11 +11,14 @@ namespace {
 // out[c][r] = in[r][c]; 64x64 tiles through LDS, 16-byte accesses on both sides.
 // LDS tile is [64 rows][64 + 8 cols] bf16: the 16-byte pad staggers the column reads across banks.
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                        int64_t R, int C, int64_t ld_in, int64_t ld_out) {
+                                                        int64_t R, int C, int64_t ld_in, int64_t ld_out,
+                                                        int64_t s_in, int64_t s_out) {
   __shared__ bf16_t tile[64][72];
   const int t = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
+  in += (int64_t)blockIdx.z * s_in;
+  out += (int64_t)blockIdx.z * s_out;
   // load: 8 threads cover one 64-column row (16 B each); 32 rows per pass
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -173,15 +176,16 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, void* __r
 }  // namespace
 
 extern "C" int lbmk_transpose(const void* in, void* out, int64_t R, int C, int64_t ld_in, int64_t ld_out,
-                              void* stream) {
+                              int batch, int64_t s_in, int64_t s_out, void* stream) {
   LBMK_REQUIRE(in && out, "transpose: null pointer");
   LBMK_REQUIRE(R > 0 && C > 0 && R % 8 == 0 && C % 8 == 0, "transpose: R=%lld C=%d must be multiples of 8", (long long)R, C);
   LBMK_REQUIRE(ld_in >= C && ld_out >= R && ld_in % 8 == 0 && ld_out % 8 == 0, "transpose: leading dims");
   LBMK_REQUIRE(lbmk_aligned(in, 16) && lbmk_aligned(out, 16), "transpose: misaligned");
   LBMK_REQUIRE((R + 63) / 64 < (1LL << 31) && (C + 63) / 64 <= 65535, "transpose: grid");
-  dim3 grid((unsigned)((R + 63) / 64), (unsigned)((C + 63) / 64));
+  LBMK_REQUIRE(batch >= 1 && batch <= 65535 && s_in % 8 == 0 && s_out % 8 == 0, "transpose: batch %d / strides", batch);
+  dim3 grid((unsigned)((R + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)batch);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, R, C,
-                     ld_in, ld_out);
+                     ld_in, ld_out, s_in, s_out);
   return lbmk_check_launch("transpose");
 }
 
@@ -246,4 +250,452 @@ extern "C" int lbmk_colsum(const void* x, void* out, float* scratch, int64_t row
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((GN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch,
                      out, GN, nseg, out_dtype);
   return lbmk_check_launch("colsum");
+}
+
+// ================================================================================================
+// Normalisation / activation / softmax / loss backward (HBM-bound)
+// ================================================================================================
+namespace {
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// d/dz silu(z)
+__device__ __forceinline__ float dsilu_f(float z) { const float s = sigmoid_f(z); return s * (1.f + z * (1.f - s)); }
+// d/dg gelu_erf(g) = Phi(g) + g * phi(g)
+__device__ __forceinline__ float dgelu_erf_f(float g) {
+  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+// ---- GroupNorm(+SiLU) backward -------------------------------------------------------------------
+// pass 1: per (image, row slab, channel):  s1 = sum dz,  s2 = sum dz * xhat   (dz = dy * silu'(z) when fused)
+// thread mapping as in the forward statistics pass: a thread owns one 8-channel chunk and strides rows.
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ partial,
+                                                           int HW, int C, int G, int rows_per_slab, int nslab) {
+  extern __shared__ float sm[];   // [C8 chunk in block][16]: s1[8], s2[8]
+  const int t = threadIdx.x;
+  const int nch = C >> 3;                 // 8-channel chunks per row
+  const int cpb = nch < 256 ? nch : 256;  // chunks handled per block pass (grid.y covers the rest)
+  const int rpp = 256 / cpb;
+  const int chunk = blockIdx.y * cpb + t % cpb, rl = t / cpb;
+  const int slab = blockIdx.x, b = blockIdx.z;
+  const int cpg = C / G;
+  for (int i = t; i < cpb * 16; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  if (chunk < nch && rl < rpp) {
+    const int c0 = chunk * 8;
+    float a[8], sh[8], mu[8], rs[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c0 + e) / cpg;
+      mu[e] = stats[((int64_t)b * G + g) * 2];
+      rs[e] = stats[((int64_t)b * G + g) * 2 + 1];
+      a[e] = gamma ? gamma[c0 + e] : 1.f;
+      sh[e] = beta ? beta[c0 + e] : 0.f;
+      s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const int r0 = slab * rows_per_slab, r1 = min(r0 + rows_per_slab, HW);
+    const int64_t base = ((int64_t)b * HW) * C + c0;
+    for (int r = r0 + rl; r < r1; r += rpp) {
+      const u16x8 xv = *(const u16x8*)(x + base + (int64_t)r * C);
+      const u16x8 dv = *(const u16x8*)(dy + base + (int64_t)r * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (bf2f(xv.v[e]) - mu[e]) * rs[e];
+        float dz = bf2f(dv.v[e]);
+        if (SILU) dz *= dsilu_f(xh * a[e] + sh[e]);
+        s1[e] += dz;
+        s2[e] += dz * xh;
+      }
+    }
+    float* dst = sm + (t % cpb) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(dst + e, s1[e]); atomicAdd(dst + 8 + e, s2[e]); }
+  }
+  __syncthreads();
+  // partial[((b*nslab + slab)*C + c)*2 + {0,1}]
+  for (int i = t; i < cpb * 8; i += 256) {
+    const int ck = i >> 3, e = i & 7;
+    const int c = (blockIdx.y * cpb + ck) * 8 + e;
+    if (c < C) {
+      float* p = partial + (((int64_t)b * nslab + slab) * C + c) * 2;
+      p[0] = sm[ck * 16 + e];
+      p[1] = sm[ck * 16 + 8 + e];
+    }
+  }
+}
+
+// pass 2a: bc[b][c][2] = sum over slabs
+__global__ void gn_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ bc, int B, int C, int nslab) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over B*C
+  if (i >= (int64_t)B * C) return;
+  const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nslab; ++k) {
+    const float* p = partial + (((int64_t)b * nslab + k) * C + c) * 2;
+    s1 += p[0]; s2 += p[1];
+  }
+  bc[i * 2] = (float)s1;
+  bc[i * 2 + 1] = (float)s2;
+}
+
+// pass 2b: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1;  gsum[b][g] = {sum_c gamma*s1, sum_c gamma*s2} / n
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ bc, const float* __restrict__ gamma,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ gsum,
+                                       int B, int C, int G, float inv_n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C) {
+    float a = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; ++b) { bsum += bc[((int64_t)b * C + i) * 2]; a += bc[((int64_t)b * C + i) * 2 + 1]; }
+    if (dgamma) dgamma[i] = a;
+    if (dbeta) dbeta[i] = bsum;
+  }
+  if (i < B * G) {
+    const int b = i / G, g = i - b * G, cpg = C / G;
+    float A = 0.f, Bq = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const float ga = gamma ? gamma[c] : 1.f;
+      A += ga * bc[((int64_t)b * C + c) * 2];
+      Bq += ga * bc[((int64_t)b * C + c) * 2 + 1];
+    }
+    gsum[i * 2] = A * inv_n;
+    gsum[i * 2 + 1] = Bq * inv_n;
+  }
+}
+
+// pass 3: dx = rstd * (gamma*dz - A/n - xhat * Bq/n)
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, const float* __restrict__ stats,
+                                                           const float* __restrict__ gsum, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int HW, int C, int G, int64_t total8) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 8-channel chunk of one pixel
+  if (gid >= total8) return;
+  const int nch = C >> 3;
+  const int chunk = (int)(gid % nch);
+  const int64_t row = gid / nch;            // b*HW + pixel
+  const int b = (int)(row / HW);
+  const int c0 = chunk * 8, cpg = C / G;
+  const u16x8 xv = *(const u16x8*)(x + row * C + c0);
+  const u16x8 dv = *(const u16x8*)(dy + row * C + c0);
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = (c0 + e) / cpg;
+    const float mu = stats[((int64_t)b * G + g) * 2], rs = stats[((int64_t)b * G + g) * 2 + 1];
+    const float A = gsum[((int64_t)b * G + g) * 2], Bq = gsum[((int64_t)b * G + g) * 2 + 1];
+    const float ga = gamma ? gamma[c0 + e] : 1.f, be = beta ? beta[c0 + e] : 0.f;
+    const float xh = (bf2f(xv.v[e]) - mu) * rs;
+    float dz = bf2f(dv.v[e]);
+    if (SILU) dz *= dsilu_f(xh * ga + be);
+    o.v[e] = f2bf(rs * (ga * dz - A - xh * Bq));
+  }
+  *(u16x8*)(dx + row * C + c0) = o;
+}
+
+// ---- LayerNorm backward: one wave per row, a block walks `rows_per_block` rows and keeps dgamma / dbeta partials
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                     bf16_t* __restrict__ dx, const float* __restrict__ gamma,
+                                                     float* __restrict__ partial, int rows, int C, float eps,
+                                                     int rows_per_block) {
+  extern __shared__ float sm[];     // [2][C] block partials of dgamma, dbeta
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nchunks = C >> 3;
+  for (int i = t; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  float dg[NC][8], db[NC][8], ga[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dg[i][e] = 0.f; db[i][e] = 0.f;
+      const int c = (lane + 64 * i) * 8 + e;
+      ga[i][e] = (gamma && c < C) ? gamma[c] : 1.f;
+    }
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(r_begin + rows_per_block, rows);
+  for (int row = r_begin + wave; row < r_end; row += 4) {
+    float xv[NC][8], dv[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunks) {
+        const u16x8 u = *(const u16x8*)(x + (int64_t)row * C + c * 8);
+        const u16x8 d = *(const u16x8*)(dy + (int64_t)row * C + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[i][e] = bf2f(u.v[e]); dv[i][e] = bf2f(d.v[e]); s += xv[i][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[i][e] = 0.f; dv[i][e] = 0.f; }
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (lane + 64 * i < nchunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; q += d * d; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (lane + 64 * i < nchunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[i][e] - mean) * rstd;
+          xv[i][e] = xh;
+          const float g = ga[i][e] * dv[i][e];
+          m1 += g; m2 += g * xh;
+          dg[i][e] += dv[i][e] * xh;
+          db[i][e] += dv[i][e];
+        }
+      }
+    m1 = wave_sum(m1) / (float)C;
+    m2 = wave_sum(m2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunks) {
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = f2bf(rstd * (ga[i][e] * dv[i][e] - m1 - xv[i][e] * m2));
+        *(u16x8*)(dx + (int64_t)row * C + c * 8) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&sm[c * 8 + e], dg[i][e]); atomicAdd(&sm[C + c * 8 + e], db[i][e]); }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < 2 * C; i += 256) partial[(int64_t)blockIdx.x * 2 * C + i] = sm[i];
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------
+__global__ void silu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const u16x8 xv = ((const u16x8*)x)[i], dv = ((const u16x8*)dy)[i];
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.v[e] = f2bf(bf2f(dv.v[e]) * dsilu_f(bf2f(xv.v[e])));
+  ((u16x8*)dx)[i] = o;
+}
+
+// h: [rows][2F] (value | gate);  y[r][f] = h[r][f] * gelu(h[r][F+f])
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ y, int64_t rows, int F) {
+  const int f8 = F >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * f8) return;
+  const int64_t r = i / f8;
+  const int c = (int)(i - r * f8) * 8;
+  const u16x8 a = *(const u16x8*)(h + r * 2 * F + c), g = *(const u16x8*)(h + r * 2 * F + F + c);
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.v[e] = f2bf(bf2f(a.v[e]) * gelu_erf_f(bf2f(g.v[e])));
+  *(u16x8*)(y + r * F + c) = o;
+}
+
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dh,
+                                 int64_t rows, int F) {
+  const int f8 = F >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * f8) return;
+  const int64_t r = i / f8;
+  const int c = (int)(i - r * f8) * 8;
+  const u16x8 a = *(const u16x8*)(h + r * 2 * F + c), g = *(const u16x8*)(h + r * 2 * F + F + c);
+  const u16x8 d = *(const u16x8*)(dy + r * F + c);
+  u16x8 oa, og;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float gv = bf2f(g.v[e]), dv = bf2f(d.v[e]);
+    oa.v[e] = f2bf(dv * gelu_erf_f(gv));
+    og.v[e] = f2bf(dv * bf2f(a.v[e]) * dgelu_erf_f(gv));
+  }
+  *(u16x8*)(dh + r * 2 * F + c) = oa;
+  *(u16x8*)(dh + r * 2 * F + F + c) = og;
+}
+
+// dS[r][j] = scale * P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]);  one block per row; P bf16, dP f32, dS bf16
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const bf16_t* __restrict__ p, const float* __restrict__ dp,
+                                                               bf16_t* __restrict__ ds, int cols, float scale) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const bf16_t* pr = p + row * cols;
+  const float* dr = dp + row * cols;
+  float s = 0.f;
+  for (int j = t * 4; j < cols; j += 1024) {
+    const u16x4 pv = *(const u16x4*)(pr + j);
+    const f32x4 dv = *(const f32x4*)(dr + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += bf2f(pv.v[e]) * dv[e];
+  }
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  for (int j = t * 4; j < cols; j += 1024) {
+    const u16x4 pv = *(const u16x4*)(pr + j);
+    const f32x4 dv = *(const f32x4*)(dr + j);
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = f2bf(scale * bf2f(pv.v[e]) * (dv[e] - dot));
+    *(u16x4*)(ds + row * cols + j) = o;
+  }
+}
+
+// d pred of the per-sample latent loss: g[b] * 2 (pred - tgt) m^2 / n  (l2)  or  g[b] * sign(pred - tgt) |m| / n  (l1)
+template <typename TP, typename TZ>
+__global__ void latent_loss_bwd_kernel(const TP* __restrict__ pred, const TZ* __restrict__ z_src, const TZ* __restrict__ z,
+                                       const uint8_t* __restrict__ mask, const float* __restrict__ gout, TP* __restrict__ dpred,
+                                       int64_t per_sample, int64_t total, int l1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / per_sample);
+  const float m = mask ? (mask[i] ? 1.f : 0.f) : 1.f;
+  // the forward pass forms target = z_src - z in the latent dtype
+  const float tgt = (float)(TZ)((float)z_src[i] - (float)z[i]);
+  const float d = ((float)pred[i] - tgt) * m;
+  const float g = gout[b] / (float)per_sample;
+  const float v = l1 ? g * m * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : g * 2.f * d * m;
+  dpred[i] = (TP)v;
+}
+
+}  // namespace
+
+extern "C" int64_t lbmk_groupnorm_bwd_scratch_floats(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C % 8 || G <= 0 || C % G) return -1;
+  int nslab = (HW + 511) / 512;
+  if (nslab > 256) nslab = 256;
+  return (int64_t)B * nslab * C * 2 + (int64_t)B * C * 2 + (int64_t)B * G * 2;
+}
+
+extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
+                                  const float* beta, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
+                                  int G, int silu, void* stream) {
+  LBMK_REQUIRE(x && dy && dx && stats && scratch, "groupnorm_bwd: null pointer");
+  LBMK_REQUIRE(lbmk_groupnorm_bwd_scratch_floats(B, HW, C, G) > 0 && B <= 65535, "groupnorm_bwd: B=%d HW=%d C=%d G=%d", B, HW, C, G);
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(dy, 16) && lbmk_aligned(dx, 16), "groupnorm_bwd: misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  int nslab = (HW + 511) / 512;
+  if (nslab > 256) nslab = 256;
+  const int rows_per_slab = (HW + nslab - 1) / nslab;
+  nslab = (HW + rows_per_slab - 1) / rows_per_slab;
+  float* partial = scratch;
+  float* bc = scratch + (int64_t)B * ((HW + 511) / 512 > 256 ? 256 : (HW + 511) / 512) * C * 2;
+  float* gsum = bc + (int64_t)B * C * 2;
+  const int nch = C / 8, cpb = nch < 256 ? nch : 256;
+  dim3 grid(nslab, (nch + cpb - 1) / cpb, B);
+  const size_t shm = (size_t)cpb * 16 * sizeof(float);
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
+                       beta, partial, HW, C, G, rows_per_slab, nslab);
+  else
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
+                       beta, partial, HW, C, G, rows_per_slab, nslab);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(((int64_t)B * C + 255) / 256)), dim3(256), 0, s, partial, bc, B, C, nslab);
+  const int nfin = C > B * G ? C : B * G;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, bc, gamma, dgamma, dbeta, gsum, B, C, G,
+                     1.0f / ((float)HW * (float)(C / G)));
+  const int64_t total8 = (int64_t)B * HW * nch;
+  LBMK_REQUIRE((total8 + 255) / 256 < (1LL << 31), "groupnorm_bwd: grid");
+  if (silu)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8);
+  return lbmk_check_launch("groupnorm_bwd");
+}
+
+extern "C" int64_t lbmk_layernorm_bwd_scratch_floats(int rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 8 || C > 2048) return -1;
+  int nblk = (rows + 63) / 64;
+  if (nblk > 1024) nblk = 1024;
+  return (int64_t)nblk * 2 * C;
+}
+
+extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma_dbeta,
+                                  float* scratch, int rows, int C, float eps, void* stream) {
+  LBMK_REQUIRE(x && dy && dx && scratch, "layernorm_bwd: null pointer");
+  const int64_t nfl = lbmk_layernorm_bwd_scratch_floats(rows, C);
+  LBMK_REQUIRE(nfl > 0, "layernorm_bwd: rows=%d C=%d (C %% 8 == 0, C <= 2048)", rows, C);
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(dy, 16) && lbmk_aligned(dx, 16), "layernorm_bwd: misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = (int)(nfl / (2 * C));
+  const int rpb = (rows + nblk - 1) / nblk;
+  const int nc = (C / 8 + 63) / 64;
+  const size_t shm = (size_t)2 * C * sizeof(float);
+#define LN_BWD(NC) hipLaunchKernelGGL(ln_bwd_kernel<NC>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, \
+                                      (bf16_t*)dx, gamma, scratch, rows, C, eps, rpb)
+  switch (nc) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    default: LN_BWD(4); break;
+  }
+#undef LN_BWD
+  // block partials are [nblk][2][C]: row 0 dgamma, row 1 dbeta
+  if (dgamma_dbeta)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, scratch, (void*)dgamma_dbeta,
+                       (int64_t)2 * C, nblk, 1);
+  return lbmk_check_launch("layernorm_bwd");
+}
+
+extern "C" int lbmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  LBMK_REQUIRE(x && dy && dx && n > 0 && n % 8 == 0, "silu_bwd: n=%lld", (long long)n);
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+  return lbmk_check_launch("silu_bwd");
+}
+
+extern "C" int lbmk_geglu_fwd(const void* h, void* y, int64_t rows, int F, void* stream) {
+  LBMK_REQUIRE(h && y && rows > 0 && F > 0 && F % 8 == 0, "geglu_fwd: rows=%lld F=%d", (long long)rows, F);
+  const int64_t n = rows * (F / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     (bf16_t*)y, rows, F);
+  return lbmk_check_launch("geglu_fwd");
+}
+
+extern "C" int lbmk_geglu_bwd(const void* h, const void* dy, void* dh, int64_t rows, int F, void* stream) {
+  LBMK_REQUIRE(h && dy && dh && rows > 0 && F > 0 && F % 8 == 0, "geglu_bwd: rows=%lld F=%d", (long long)rows, F);
+  const int64_t n = rows * (F / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     (const bf16_t*)dy, (bf16_t*)dh, rows, F);
+  return lbmk_check_launch("geglu_bwd");
+}
+
+extern "C" int lbmk_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, float scale, void* stream) {
+  LBMK_REQUIRE(p && dp && ds && rows > 0 && rows < (1LL << 31) && cols > 0 && cols % 4 == 0, "softmax_bwd_rows: rows/cols");
+  LBMK_REQUIRE(lbmk_aligned(p, 8) && lbmk_aligned(dp, 16) && lbmk_aligned(ds, 8), "softmax_bwd_rows: misaligned");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, dp,
+                     (bf16_t*)ds, cols, scale);
+  return lbmk_check_launch("softmax_bwd_rows");
+}
+
+extern "C" int lbmk_latent_loss_bwd(const void* pred, const void* z_src, const void* z, const uint8_t* mask,
+                                    const float* gout, void* dpred, int B, int64_t per_sample, int l1, int pred_dtype,
+                                    int z_dtype, void* stream) {
+  LBMK_REQUIRE(pred && z_src && z && gout && dpred && B > 0 && per_sample > 0, "latent_loss_bwd: arguments");
+  const int64_t total = (int64_t)B * per_sample;
+  dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define LLB(TP, TZ) hipLaunchKernelGGL((latent_loss_bwd_kernel<TP, TZ>), grid, dim3(256), 0, s, (const TP*)pred, (const TZ*)z_src, \
+                                       (const TZ*)z, mask, gout, (TP*)dpred, per_sample, total, l1)
+  if (pred_dtype == 0 && z_dtype == 0) LLB(__bf16, __bf16);
+  else if (pred_dtype == 0 && z_dtype == 1) LLB(__bf16, float);
+  else if (pred_dtype == 1 && z_dtype == 0) LLB(float, __bf16);
+  else if (pred_dtype == 1 && z_dtype == 1) LLB(float, float);
+  else LBMK_REQUIRE(false, "latent_loss_bwd: dtype codes %d %d", pred_dtype, z_dtype);
+#undef LLB
+  return lbmk_check_launch("latent_loss_bwd");
 }

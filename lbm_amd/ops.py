@@ -256,9 +256,10 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 1.0,
             bias_m: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
-            residual: Optional[torch.Tensor] = None, tile: int = -1) -> torch.Tensor:
+            residual: Optional[torch.Tensor] = None, tile: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Batched out[z] = alpha * a[z] @ b[z]^T.  a: bf16 [Z, M, K] or [M, K]; b: bf16 [Z, N, K] or
-    [N, K]; rows contiguous, K a multiple of 64.  bias_m: f32 [M] per output row; bias_n: f32 [N]."""
+    [N, K]; rows contiguous, K a multiple of 64.  bias_m: f32 [M] per output row; bias_n: f32 [N].
+    ``out``: optional preallocated [Z, M, N] / [M, N] view (unit column stride; row and batch strides free)."""
     _need_gpu(a, b)
     assert a.dtype == bf16 and b.dtype == bf16 and a.stride(-1) == 1 and b.stride(-1) == 1
     Z = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
@@ -266,7 +267,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     N = b.shape[-2]
     assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0
     shape = (Z, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
-    out = torch.empty(*shape, dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(*shape, dtype=out_dtype, device=a.device)
+    else:
+        assert tuple(out.shape) == shape and out.stride(-1) == 1 and out.is_cuda
+        out_dtype = out.dtype
     d = IgemmDesc()
     d.a, d.w, d.out = a.data_ptr(), b.data_ptr(), out.data_ptr()
     assert not (bias_m is not None and bias_n is not None)
@@ -279,13 +284,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     d.IH = d.IW = d.OH = d.OW = 1
     d.KH = d.KW = d.stride = 1
     d.pad_t = d.pad_l = d.up2 = 0
-    d.ldo, d.rowvec_ld = N, 0
+    d.ldo, d.rowvec_ld = out.stride(-2), 0
     d.ldr = residual.stride(-2) if residual is not None else 0
     d.act, d.out_f32, d.alpha = ACT_NONE, 1 if out_dtype == torch.float32 else 0, alpha
     d.batch = Z
     d.sa = a.stride(0) if a.dim() == 3 else 0
     d.sw = b.stride(0) if b.dim() == 3 else 0
-    d.so = M * N if len(shape) == 3 else 0
+    d.so = out.stride(0) if len(shape) == 3 else 0
     d.sr = residual.stride(0) if (residual is not None and residual.dim() == 3) else 0
     d.tile = tile
     _igemm(d)
@@ -522,12 +527,14 @@ def tile_finalize(acc, wsum, out_dtype=torch.float32):
 # backward (training) path: operand re-layout and reductions; the GEMMs are lbmk_igemm launches
 # --------------------------------------------------------------------------------------
 def transpose(x: torch.Tensor) -> torch.Tensor:
-    """bf16 [R, C] (row stride >= C) -> contiguous [C, R]; R and C multiples of 8."""
+    """bf16 [R, C] or [Z, R, C] (row stride >= C) -> contiguous [C, R] / [Z, C, R]; R and C multiples of 8."""
     _need_gpu(x)
-    assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
-    R, Cc = x.shape
-    out = torch.empty(Cc, R, dtype=bf16, device=x.device)
-    check(lib.lbmk_transpose(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(0), R, _stream()), "lbmk_transpose")
+    assert x.dtype == bf16 and x.dim() in (2, 3) and x.stride(-1) == 1
+    R, Cc = x.shape[-2], x.shape[-1]
+    Z = x.shape[0] if x.dim() == 3 else 1
+    out = torch.empty(*x.shape[:-2], Cc, R, dtype=bf16, device=x.device)
+    check(lib.lbmk_transpose(x.data_ptr(), out.data_ptr(), R, Cc, x.stride(-2), R, Z,
+                             x.stride(0) if x.dim() == 3 else 0, Cc * R, _stream()), "lbmk_transpose")
     return out
 
 
@@ -603,3 +610,105 @@ def col2im(dcol: torch.Tensor, B: int, IH: int, IW: int, OH: int, OW: int, cin: 
     check(lib.lbmk_col2im(dcol.data_ptr(), dx.data_ptr(), B, IH, IW, OH, OW, KH, KW, stride, pad[0], pad[1],
                           1 if up2 else 0, cin, dcol.stride(0), cin, _stream()), "lbmk_col2im")
     return dx
+
+
+def groupnorm_train(x, gamma, beta, groups: int, eps: float, silu: bool):
+    """GroupNorm(+SiLU) that also returns the [B, G, 2] (mean, rstd) statistics for the backward pass."""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.is_contiguous()
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    nfl = lib.lbmk_groupnorm_scratch_floats(B, HW, Cc, groups)
+    if nfl < 0:
+        raise _C.LbmkError(f"groupnorm: unsupported shape B={B} HW={HW} C={Cc} G={groups}")
+    buf = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib.lbmk_groupnorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), buf.data_ptr(),
+                             B, HW, Cc, groups, eps, 1 if silu else 0, _stream()), "lbmk_groupnorm")
+    return y, buf[nfl - B * groups * 2:].view(B, groups, 2)
+
+
+def groupnorm_bwd(x, dy, stats, gamma, beta, groups: int, silu: bool):
+    """-> dx bf16, dgamma f32 [C], dbeta f32 [C]"""
+    _need_gpu(x, dy, stats)
+    assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous() and stats.is_contiguous()
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    nfl = lib.lbmk_groupnorm_bwd_scratch_floats(B, HW, Cc, groups)
+    if nfl < 0:
+        raise _C.LbmkError(f"groupnorm_bwd: unsupported shape B={B} HW={HW} C={Cc} G={groups}")
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    check(lib.lbmk_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), stats.data_ptr(), _ptr(gamma), _ptr(beta),
+                                 dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, HW, Cc, groups, 1 if silu else 0,
+                                 _stream()), "lbmk_groupnorm_bwd")
+    return dx, dg, db
+
+
+def layernorm_bwd(x, dy, gamma, eps: float = 1e-5):
+    """-> dx bf16, dgamma f32 [C], dbeta f32 [C]"""
+    _need_gpu(x, dy)
+    assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous()
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    nfl = lib.lbmk_layernorm_bwd_scratch_floats(rows, Cc)
+    if nfl < 0:
+        raise _C.LbmkError(f"layernorm_bwd: unsupported shape rows={rows} C={Cc}")
+    scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgb = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+    check(lib.lbmk_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(gamma), dgb.data_ptr(),
+                                 scratch.data_ptr(), rows, Cc, eps, _stream()), "lbmk_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+def silu_bwd(x, dy):
+    _need_gpu(x, dy)
+    assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous() and x.numel() % 8 == 0
+    dx = torch.empty_like(x)
+    check(lib.lbmk_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "lbmk_silu_bwd")
+    return dx
+
+
+def geglu_fwd(h):
+    _need_gpu(h)
+    assert h.dtype == bf16 and h.is_contiguous() and h.shape[-1] % 16 == 0
+    F = h.shape[-1] // 2
+    y = torch.empty(*h.shape[:-1], F, dtype=bf16, device=h.device)
+    check(lib.lbmk_geglu_fwd(h.data_ptr(), y.data_ptr(), h.numel() // (2 * F), F, _stream()), "lbmk_geglu_fwd")
+    return y
+
+
+def geglu_bwd(h, dy):
+    _need_gpu(h, dy)
+    assert h.dtype == bf16 and dy.dtype == bf16 and h.is_contiguous() and dy.is_contiguous()
+    F = h.shape[-1] // 2
+    dh = torch.empty_like(h)
+    check(lib.lbmk_geglu_bwd(h.data_ptr(), dy.data_ptr(), dh.data_ptr(), h.numel() // (2 * F), F, _stream()), "lbmk_geglu_bwd")
+    return dh
+
+
+def softmax_bwd_rows(p, dp, scale: float):
+    """p bf16 [..., cols], dp f32 same shape -> dS bf16 = scale * p * (dp - rowsum(dp * p))"""
+    _need_gpu(p, dp)
+    assert p.dtype == bf16 and dp.dtype == torch.float32 and p.is_contiguous() and dp.is_contiguous() and p.shape == dp.shape
+    cols = p.shape[-1]
+    ds = torch.empty_like(p)
+    check(lib.lbmk_softmax_bwd_rows(p.data_ptr(), dp.data_ptr(), ds.data_ptr(), p.numel() // cols, cols, scale, _stream()),
+          "lbmk_softmax_bwd_rows")
+    return ds
+
+
+def latent_loss_bwd(pred, z_src, z, mask, gout, l1: bool):
+    _need_gpu(pred, z_src, z, gout)
+    B = pred.shape[0]
+    per = pred.numel() // B
+    pred, z_src, z = pred.contiguous(), z_src.contiguous(), z.contiguous()
+    m = None if mask is None else mask.to(torch.uint8).expand_as(pred).contiguous()
+    gout = gout.reshape(B).float().contiguous()
+    dpred = torch.empty_like(pred)
+    check(lib.lbmk_latent_loss_bwd(pred.data_ptr(), z_src.data_ptr(), z.data_ptr(), _ptr(m), gout.data_ptr(), dpred.data_ptr(),
+                                   B, per, 1 if l1 else 0, _dt(pred), _dt(z), _stream()), "lbmk_latent_loss_bwd")
+    return dpred

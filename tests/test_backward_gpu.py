@@ -112,3 +112,94 @@ def test_conv_backward_rowvec_residual(cuda, gen):
     assert rel_l2(xg.grad, xr.grad) < 6e-3
     assert rel_l2(rvg.grad, rvr.grad) < 6e-3
     assert torch.equal(rg.grad.cpu(), dy)
+
+
+@pytest.mark.parametrize("B,H,W,C,silu", [(2, 16, 16, 320, True), (3, 8, 8, 1280, True), (2, 12, 20, 64, False), (2, 32, 32, 2560, True)])
+def test_groupnorm_backward(cuda, gen, B, H, W, C, silu):
+    from lbm_amd.autograd import GroupNormFn
+    x, dy = randbf(gen, B, H, W, C), randbf(gen, B, H, W, C)
+    gam, bet = (torch.rand(C, generator=gen) + 0.5).to(BF), torch.randn(C, generator=gen).to(BF)
+    xr, gr, br = x.float().requires_grad_(), gam.float().requires_grad_(), bet.float().requires_grad_()
+    yr = F.group_norm(xr.permute(0, 3, 1, 2), 32, gr, br, 1e-5)
+    yr = (F.silu(yr) if silu else yr).permute(0, 2, 3, 1)
+    yr.backward(dy.float())
+    xg, gg, bg = x.to(cuda).requires_grad_(), gam.to(cuda).requires_grad_(), bet.to(cuda).requires_grad_()
+    y = GroupNormFn.apply(xg, gg, bg, 32, 1e-5, silu)
+    assert rel_l2(y, yr) < 5e-3
+    y.backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 6e-3
+    assert rel_l2(gg.grad, gr.grad) < 8e-3
+    assert rel_l2(bg.grad, br.grad) < 8e-3
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 640), (512, 1280), (77, 320)])
+def test_layernorm_backward(cuda, gen, rows, C):
+    from lbm_amd.autograd import LayerNormFn
+    x, dy = randbf(gen, rows, C), randbf(gen, rows, C)
+    gam, bet = (torch.rand(C, generator=gen) + 0.5).to(BF), torch.randn(C, generator=gen).to(BF)
+    xr, gr, br = x.float().requires_grad_(), gam.float().requires_grad_(), bet.float().requires_grad_()
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy.float())
+    xg, gg, bg = x.to(cuda).requires_grad_(), gam.to(cuda).requires_grad_(), bet.to(cuda).requires_grad_()
+    LayerNormFn.apply(xg, gg, bg, 1e-5).backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 6e-3
+    assert rel_l2(gg.grad, gr.grad) < 8e-3
+    assert rel_l2(bg.grad, br.grad) < 8e-3
+
+
+def test_silu_geglu_backward(cuda, gen):
+    from lbm_amd.autograd import GegluFn, SiluFn
+    x, dy = randbf(gen, 64, 320), randbf(gen, 64, 320)
+    xr = x.float().requires_grad_()
+    F.silu(xr).backward(dy.float())
+    xg = x.to(cuda).requires_grad_()
+    SiluFn.apply(xg).backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 5e-3
+    h, dyh = randbf(gen, 50, 2 * 1280), randbf(gen, 50, 1280)
+    hr = h.float().requires_grad_()
+    a, g = hr.chunk(2, -1)
+    yr = a * F.gelu(g)
+    yr.backward(dyh.float())
+    hg = h.to(cuda).requires_grad_()
+    y = GegluFn.apply(hg)
+    assert rel_l2(y, yr) < 5e-3
+    y.backward(dyh.to(cuda))
+    assert rel_l2(hg.grad, hr.grad) < 5e-3
+
+
+@pytest.mark.parametrize("B,N,H,D", [(2, 256, 5, 64), (1, 1024, 2, 64), (2, 64, 4, 40)])
+def test_attention_backward(cuda, gen, B, N, H, D):
+    from lbm_amd.autograd import AttentionFn
+    C = H * D
+    q, k, v, do = (randbf(gen, B, N, C) for _ in range(4))
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    def heads(t):
+        return t.view(B, N, H, D).transpose(1, 2)
+    orf = F.scaled_dot_product_attention(heads(qr), heads(kr), heads(vr)).transpose(1, 2).reshape(B, N, C)
+    orf.backward(do.float())
+    qg, kg, vg = (t.to(cuda).requires_grad_() for t in (q, k, v))
+    o = AttentionFn.apply(qg, kg, vg, H, D, D ** -0.5)
+    assert rel_l2(o, orf) < 6e-3
+    o.backward(do.to(cuda))
+    assert rel_l2(vg.grad, vr.grad) < 8e-3
+    assert rel_l2(qg.grad, qr.grad) < 1e-2
+    assert rel_l2(kg.grad, kr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("l1", [False, True])
+def test_latent_loss_backward(cuda, gen, l1):
+    from lbm_amd.autograd import LatentLossFn
+    B = 3
+    pred, zs, z = randbf(gen, B, 4, 16, 16), randbf(gen, B, 4, 16, 16), randbf(gen, B, 4, 16, 16)
+    mask = (torch.rand(B, 1, 16, 16, generator=gen) > 0.3)
+    w = torch.tensor([0.5, 1.0, 2.0])
+    pr = pred.float().requires_grad_()
+    tgt = (zs - z).float()
+    m = mask.float()
+    d = pr * m - tgt * m
+    per = (d.abs() if l1 else d ** 2).mean(dim=(1, 2, 3))
+    (per * w).sum().backward()
+    pg = pred.to(cuda).requires_grad_()
+    out = LatentLossFn.apply(pg, zs.to(cuda), z.to(cuda), mask.to(cuda), l1)
+    assert rel_l2(out, per) < 1e-3
+    (out * w.to(cuda)).sum().backward()
+    assert rel_l2(pg.grad, pr.grad) < 5e-3
