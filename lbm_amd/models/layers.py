@@ -106,6 +106,9 @@ class HipGroupNorm(nn.GroupNorm, _Cached):
                             lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
 
     def forward(self, x, silu: bool = False):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            from ..autograd import GroupNormFn
+            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu)
         g, b = self.affine_f32()
         return ops.groupnorm(x, g, b, self.num_groups, self.eps, silu)
 
@@ -116,8 +119,17 @@ class HipLayerNorm(nn.LayerNorm, _Cached):
                             lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            from ..autograd import LayerNormFn
+            return LayerNormFn.apply(x.contiguous(), self.weight, self.bias, self.eps)
         g, b = self.affine_f32()
         return ops.layernorm(x, g, b, self.eps)
+
+
+def training(*tensors_or_params) -> bool:
+    """True when autograd is recording and any operand wants a gradient: modules then take the
+    unfused, differentiable route (every op a torch.autograd.Function over the HIP kernels)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors_or_params)
 
 
 def fused_rows(module: _Cached, name: str, layers, bias: bool):

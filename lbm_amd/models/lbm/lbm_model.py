@@ -104,13 +104,19 @@ class LBMModel(BaseModel):
         prediction = self.denoiser(sample=noisy_sample, timestep=timestep, conditioning=conditioning, *args, **kwargs)
 
         neg_sig = -sigmas.reshape(-1)
-        denoised_sample = ops.axpy_rows(noisy_sample, prediction.contiguous(), neg_sig)
+        denoised_sample = ops.axpy_rows(noisy_sample, prediction.detach().contiguous(), neg_sig)
 
         if self.latent_loss_weight > 0:
             if self.latent_loss_type not in ("l2", "l1"):
                 raise NotImplementedError(f"Loss type {self.latent_loss_type} not implemented")
-            loss = ops.latent_loss(prediction.contiguous(), z_source, z, valid_mask_for_latent,
-                                   l1=self.latent_loss_type == "l1")
+            if prediction.requires_grad:
+                # training: the loss is differentiable w.r.t. the prediction (kernel lbmk_latent_loss_bwd)
+                from ...autograd import LatentLossFn
+                loss = LatentLossFn.apply(prediction.contiguous(), z_source, z, valid_mask_for_latent,
+                                          self.latent_loss_type == "l1")
+            else:
+                loss = ops.latent_loss(prediction.contiguous(), z_source, z, valid_mask_for_latent,
+                                       l1=self.latent_loss_type == "l1")
             latent_recon_loss = loss.mean()
         else:
             loss = torch.zeros(z.shape[0], device=z.device)

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..layers import HipConv2d, HipGroupNorm, HipLayerNorm, HipLinear, _Cached, fused_rows
+from ..layers import HipConv2d, HipGroupNorm, HipLayerNorm, HipLinear, _Cached, fused_rows, training
 
 
 class UNet2DConditionOutput:
@@ -85,6 +85,13 @@ class Attention(nn.Module, _Cached):
         if self.dim_head not in (40, 64, 80, 160):
             raise NotImplementedError(f"flash attention kernels cover head_dim 40/64/80/160 (got {self.dim_head})")
         C = self.inner_dim
+        if training(xn, self.to_q.weight):
+            # differentiable route: separate projections, attention with a hand-written backward
+            from ...autograd import AttentionFn
+            src = xn if ctx is None else ctx.to(torch.bfloat16).contiguous()
+            q, k, v = self.to_q(xn), self.to_k(src), self.to_v(src)
+            o = AttentionFn.apply(q, k, v, self.heads, self.dim_head, self.dim_head ** -0.5)
+            return self.to_out[0](o, residual=residual)
         if ctx is None:
             qk = ops.linear(xn, fused_rows(self, "qk", [self.to_q, self.to_k], bias=self.to_q.bias is not None))
             wv, bv = self._v_weight()
@@ -116,6 +123,9 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), HipLinear(dim * mult, dim)])
 
     def forward(self, xn, residual):
+        if training(xn, self.net[2].weight):
+            from ...autograd import GegluFn
+            return self.net[2](GegluFn.apply(self.net[0].proj(xn)), residual=residual)
         return self.net[2](self.net[0].proj(xn, geglu=True), residual=residual)
 
 
@@ -301,6 +311,10 @@ class UNet2DConditionModel(nn.Module, _Cached):
         if t.numel() == 1:
             t = t.expand(B)
         t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in)
+        if training(self.time_embedding.linear_1.weight):
+            from ...autograd import SiluFn
+            e = SiluFn.apply(self.time_embedding.linear_2(SiluFn.apply(self.time_embedding.linear_1(t_emb))))
+            return {id(r): r.time_emb_proj(e) for r in self._resnets()}
         e = self.time_embedding.linear_1(t_emb, act=ops.ACT_SILU)
         e = self.time_embedding.linear_2(e, act=ops.ACT_SILU)        # silu(temb): the only form the resnets consume
         resnets = self._resnets()
@@ -320,8 +334,13 @@ class UNet2DConditionModel(nn.Module, _Cached):
                 or mid_block_additional_residual is not None or down_intrablock_additional_residuals is not None:
             raise NotImplementedError("class labels / added conditions / ControlNet residuals are not used by the reference's builders")
         B = sample.shape[0]
+        train = training(sample, self.conv_in.weight)
         tv = self._time_vectors(timestep, B, sample.device)
-        x = ops.nchw_to_nhwc(sample)
+        if train and sample.requires_grad:
+            from ...autograd import NchwToNhwcFn
+            x = NchwToNhwcFn.apply(sample)
+        else:
+            x = ops.nchw_to_nhwc(sample)
         ctx = encoder_hidden_states
         h = self.conv_in(x)
         skips = [h]
@@ -340,7 +359,7 @@ class UNet2DConditionModel(nn.Module, _Cached):
         h = m.resnets[1](h, tv[id(m.resnets[1])])
         for blk in self.up_blocks:
             for j, res in enumerate(blk.resnets):
-                h = ops.concat_channels(h, skips.pop())
+                h = torch.cat([h, skips.pop()], dim=-1) if train else ops.concat_channels(h, skips.pop())
                 h = res(h, tv[id(res)])
                 if blk.has_attn:
                     h = blk.attentions[j](h, ctx)
@@ -348,5 +367,9 @@ class UNet2DConditionModel(nn.Module, _Cached):
                 h = blk.upsamplers[0](h)
         h = self.conv_norm_out(h, silu=True)
         h = self.conv_out(h)
-        out = ops.nhwc_to_nchw(h, self.config.out_channels, out_dtype=sample.dtype)
+        if train:
+            from ...autograd import NhwcToNchwFn
+            out = NhwcToNchwFn.apply(h, self.config.out_channels, sample.dtype)
+        else:
+            out = ops.nhwc_to_nchw(h, self.config.out_channels, out_dtype=sample.dtype)
         return UNet2DConditionOutput(out) if return_dict else (out,)
