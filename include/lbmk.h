@@ -234,6 +234,12 @@ int lbmk_latent_loss_bwd(const void* pred, const void* z_src, const void* z, con
                          const float* gout, void* dpred, int B, int64_t per_sample, int l1, int pred_dtype,
                          int z_dtype, void* stream);
 
+/* One AdamW step (torch.optim.AdamW semantics, the optimizer named by the reference's training configs,
+ * src/lbm/trainer/trainer.py:118-121) over a flat range: p, g bf16 [n]; m, v f32 [n]; step counts from 1;
+ * grad_scale multiplies g first (1/world_size after a summing all-reduce). */
+int lbmk_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

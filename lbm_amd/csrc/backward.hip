@@ -699,3 +699,57 @@ extern "C" int lbmk_latent_loss_bwd(const void* pred, const void* z_src, const v
 #undef LLB
   return lbmk_check_launch("latent_loss_bwd");
 }
+
+// ---- AdamW (decoupled weight decay), one fused pass over a flat parameter range ---------------------
+// torch.optim.AdamW semantics (the reference's optimizer, src/lbm/trainer/trainer.py:118-121):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// Parameters and gradients are bf16; both moments are kept in f32.
+namespace {
+__global__ void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float inv_bc1, float inv_sqrt_bc2, float grad_scale) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= n) return;
+  if (i + 8 <= n) {
+    u16x8 pv = *(const u16x8*)(p + i);
+    const u16x8 gv = *(const u16x8*)(g + i);
+    float mm[8], vv[8];
+    *(f32x4*)mm = *(const f32x4*)(m + i); *(f32x4*)(mm + 4) = *(const f32x4*)(m + i + 4);
+    *(f32x4*)vv = *(const f32x4*)(v + i); *(f32x4*)(vv + 4) = *(const f32x4*)(v + i + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gr = bf2f(gv.v[e]) * grad_scale;
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      float w = bf2f(pv.v[e]) * (1.f - lr * wd);
+      w -= lr * inv_bc1 * mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+      pv.v[e] = f2bf(w);
+    }
+    *(u16x8*)(p + i) = pv;
+    *(f32x4*)(m + i) = *(f32x4*)mm; *(f32x4*)(m + i + 4) = *(f32x4*)(mm + 4);
+    *(f32x4*)(v + i) = *(f32x4*)vv; *(f32x4*)(v + i + 4) = *(f32x4*)(vv + 4);
+  } else {
+    for (int64_t k = i; k < n; ++k) {
+      const float gr = bf2f(g[k]) * grad_scale;
+      m[k] = b1 * m[k] + (1.f - b1) * gr;
+      v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+      float w = bf2f(p[k]) * (1.f - lr * wd);
+      w -= lr * inv_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+      p[k] = f2bf(w);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int lbmk_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  LBMK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: arguments");
+  LBMK_REQUIRE(lbmk_aligned(p, 16) && lbmk_aligned(g, 16) && lbmk_aligned(m, 16) && lbmk_aligned(v, 16), "adamw: 16-byte alignment");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int64_t nthreads = (n + 7) / 8;
+  LBMK_REQUIRE((nthreads + 255) / 256 < (1LL << 31), "adamw: grid");
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
+                     (const bf16_t*)g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                     (float)(1.0 / sqrt(bc2)), grad_scale);
+  return lbmk_check_launch("adamw");
+}

@@ -712,3 +712,15 @@ def latent_loss_bwd(pred, z_src, z, mask, gout, l1: bool):
     check(lib.lbmk_latent_loss_bwd(pred.data_ptr(), z_src.data_ptr(), z.data_ptr(), _ptr(m), gout.data_ptr(), dpred.data_ptr(),
                                    B, per, 1 if l1 else 0, _dt(pred), _dt(z), _stream()), "lbmk_latent_loss_bwd")
     return dpred
+
+
+def adamw_step(p_flat, g_flat, m, v, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+               step: int = 1, grad_scale: float = 1.0):
+    """In-place AdamW update of a flat bf16 parameter range (f32 moments)."""
+    _need_gpu(p_flat, g_flat, m, v)
+    assert p_flat.dtype == bf16 and g_flat.dtype == bf16 and m.dtype == torch.float32 and v.dtype == torch.float32
+    n = p_flat.numel()
+    assert g_flat.numel() == n and m.numel() == n and v.numel() == n
+    assert p_flat.is_contiguous() and g_flat.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    check(lib.lbmk_adamw(p_flat.data_ptr(), g_flat.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, betas[0], betas[1], eps,
+                         weight_decay, step, grad_scale, _stream()), "lbmk_adamw")

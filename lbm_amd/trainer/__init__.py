@@ -1,4 +1,12 @@
 from .training_config import TrainingConfig
 from .utils import StateDictAdapter, StateDictRenamer
 
-__all__ = ["TrainingConfig", "StateDictAdapter", "StateDictRenamer"]
+__all__ = ["TrainingConfig", "StateDictAdapter", "StateDictRenamer", "TrainingPipeline"]
+
+
+def __getattr__(name):
+    # the pipeline pulls in the HIP library; keep `import lbm_amd.trainer` usable for the config classes alone
+    if name == "TrainingPipeline":
+        from .trainer import TrainingPipeline
+        return TrainingPipeline
+    raise AttributeError(name)

@@ -91,11 +91,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert _C.lib.lbmk_version() >= 1
 
 
-def test_igemm_desc_layout_matches_header():
+def test_igemm_desc_layout_matches_header(tmp_path):
+    """the ctypes mirror of lbmk_igemm_desc against the C compiler's layout of include/lbmk.h"""
+    import subprocess
     from lbm_amd._C import IgemmDesc
-    assert ctypes.sizeof(IgemmDesc) == 192
-    assert IgemmDesc.alpha.offset == 48 + 23 * 4
-    assert IgemmDesc.sa.offset == 152 and IgemmDesc.tile.offset == 184
+    names = [f[0] for f in IgemmDesc._fields_]
+    src = tmp_path / "layout.c"
+    body = "".join(f'printf("{n} %zu\\n", offsetof(lbmk_igemm_desc, {n}));' for n in names)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lbmk.h"\nint main(void){'
+                   + body + 'printf("sizeof %zu\\n", sizeof(lbmk_igemm_desc));return 0;}')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out["sizeof"]) == ctypes.sizeof(IgemmDesc)
+    for n in names:
+        assert int(out[n]) == getattr(IgemmDesc, n).offset, n
 
 
 def test_no_cpu_fallback():
