@@ -68,6 +68,10 @@ typedef struct lbmk_igemm_desc {
                            which then skips its own statistics pass over the tensor                   */
   int32_t gn_groups;    /* groups G of the consuming GroupNorm: N % G == 0, N / G in {4, 8, 16},
                            OH*OW % 64 == 0, Cin % 64 == 0, bf16 output, no GEGLU                        */
+  int32_t batch_inner;  /* 0 / 1: one batch level.  > 1: problem z = outer * batch_inner + inner, the inner
+                           index advancing a / w / out by sa2 / sw2 / so2 (attention heads inside images:
+                           outer stride = one image, inner stride = head_dim columns); no residual         */
+  int64_t sa2, sw2, so2;
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);

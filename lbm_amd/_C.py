@@ -46,6 +46,7 @@ class IgemmDesc(C.Structure):
         ("sa", i64), ("sw", i64), ("so", i64), ("sr", i64),
         ("tile", i32), ("k_order", i32),
         ("gn_partial", vp), ("gn_groups", i32),
+        ("batch_inner", i32), ("sa2", i64), ("sw2", i64), ("so2", i64),
     ]
 
 

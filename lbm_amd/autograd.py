@@ -158,26 +158,23 @@ class GegluFn(torch.autograd.Function):
         return ops.geglu_bwd(h, dy.contiguous())
 
 
+def _heads(t: torch.Tensor, H: int, D: int) -> torch.Tensor:
+    """[B, N, H*D] -> strided view [B, H, N, D] (no copy)"""
+    B, N, _ = t.shape
+    return t.view(B, N, H, D).permute(0, 2, 1, 3)
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale) v per head, heads interleaved along the channel axis ([B, N, H*D]).
-    Training path: scores are materialised one head at a time (batched over images) with the implicit-GEMM
-    kernel, probabilities are recomputed in the backward pass; q, k, v are all that is saved."""
-
-    @staticmethod
-    def _probs(q, k, h, D, scale):
-        s = ops.gemm_nt(q[..., h * D:(h + 1) * D], k[..., h * D:(h + 1) * D], out_dtype=torch.float32, alpha=scale)
-        return ops.softmax_rows(s)                                   # [B, Nq, Nk] bf16
+    Forward: the flash kernel.  Backward: probabilities are recomputed (q, k, v are all that is saved) and
+    every product is one implicit-GEMM launch batched over (image, head) through strided head views:
+      dV = P^T dO,  dP = dO V^T,  dS = scale * P * (dP - rowsum(dP * P)),  dQ = dS K,  dK = dS^T Q."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads, dim_head, scale):
-        B, Nq, C = q.shape
-        if k.shape[1] % 8 or Nq % 8:
+        if k.shape[1] % 8 or q.shape[1] % 8:
             raise NotImplementedError("training attention needs token counts that are multiples of 8")
-        o = torch.empty(B, Nq, C, dtype=bf16, device=q.device)
-        vt = ops.transpose(v)                                        # [B, C, Nk]
-        for h in range(heads):
-            p = AttentionFn._probs(q, k, h, dim_head, scale)
-            ops.gemm_nt(p, vt[:, h * dim_head:(h + 1) * dim_head, :], out=o[..., h * dim_head:(h + 1) * dim_head])
+        o = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale)
         ctx.save_for_backward(q, k, v)
         ctx.cfg = (heads, dim_head, scale)
         return o
@@ -185,19 +182,24 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v = ctx.saved_tensors
-        heads, D, scale = ctx.cfg
+        H, D, scale = ctx.cfg
         do = do.contiguous()
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        qt, kt, dot = ops.transpose(q), ops.transpose(k), ops.transpose(do)      # [B, C, N]
-        for h in range(heads):
-            sl = slice(h * D, (h + 1) * D)
-            p = AttentionFn._probs(q, k, h, D, scale)                            # [B, Nq, Nk]
-            pt = ops.transpose(p)                                                # [B, Nk, Nq]
-            ops.gemm_nt(pt, dot[:, sl, :], out=dv[..., sl])                      # dV = P^T dO
-            dp = ops.gemm_nt(do[..., sl], v[..., sl], out_dtype=torch.float32)   # dP = dO V^T
-            ds = ops.softmax_bwd_rows(p, dp, scale)                              # [B, Nq, Nk]
-            ops.gemm_nt(ds, kt[:, sl, :], out=dq[..., sl])                       # dQ = dS K
-            ops.gemm_nt(ops.transpose(ds), qt[:, sl, :], out=dk[..., sl])        # dK = dS^T Q
+        q4, k4, v4, do4 = (_heads(t, H, D) for t in (q, k, v, do))
+        p = ops.softmax_rows(ops.gemm_nt(q4, k4, out_dtype=torch.float32, alpha=scale))     # [B, H, Nq, Nk] bf16
+        # channel-major copies: [B, C, N] read as [B, H, D, N]
+        qt4 = ops.transpose(q).view(B, H, D, Nq)
+        kt4 = ops.transpose(k).view(B, H, D, Nk)
+        dot4 = ops.transpose(do).view(B, H, D, Nq)
+        pt = ops.transpose(p.view(B * H, Nq, Nk)).view(B, H, Nk, Nq)
+        ops.gemm_nt(pt, dot4, out=_heads(dv, H, D))                                          # dV = P^T dO
+        dp = ops.gemm_nt(do4, v4, out_dtype=torch.float32)                                   # dP = dO V^T
+        ds = ops.softmax_bwd_rows(p, dp, scale)
+        ops.gemm_nt(ds, kt4, out=_heads(dq, H, D))                                           # dQ = dS K
+        dst = ops.transpose(ds.view(B * H, Nq, Nk)).view(B, H, Nk, Nq)
+        ops.gemm_nt(dst, qt4, out=_heads(dk, H, D))                                          # dK = dS^T Q
         return dq, dk, dv, None, None, None
 
 

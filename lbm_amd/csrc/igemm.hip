@@ -32,10 +32,9 @@ __device__ unsigned long long igemm_dbg[65536 * 8];
 // and the residual / rowvec operands of row group i+1 are in flight while row group i is stored.
 template <int MI, int NI, bool GNS>
 __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (&acc)[MI][NI], int mbase,
-                                               int nbase, int lane, int z) {
+                                               int nbase, int lane, int64_t zo, int64_t zr) {
   const int lr = lane & 15, lq = lane >> 4;
   const int ohw = p.OH * p.OW;
-  const int64_t zo = (int64_t)z * p.so, zr = (int64_t)z * p.sr;
   const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
   const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
   const float* __restrict__ bias = p.bias;
@@ -224,9 +223,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   DBG_T(0);
   tile_origin(vblock);
 
-  const int z = blockIdx.z;
-  const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z * p.sa;
-  const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z * p.sw;
+  // batch index = outer * batch_inner + inner, each level with its own strides (heads inside images)
+  const int zin = p.batch_inner > 1 ? p.batch_inner : 1;
+  const int z_o = blockIdx.z / zin, z_i = blockIdx.z - z_o * zin;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.a + (int64_t)z_o * p.sa + (int64_t)z_i * p.sa2;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.w + (int64_t)z_o * p.sw + (int64_t)z_i * p.sw2;
+  const int64_t zo = (int64_t)z_o * p.so + (int64_t)z_i * p.so2, zr = (int64_t)z_o * p.sr;
 
   // ---- staging state ---------------------------------------------------------------------
   // Both operands are fetched with buffer_load_dwordx4 ... lds through a buffer descriptor: the
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
 
   DBG_C(7);
   DBG_T(3);
-  igemm_epilogue<MI, NI, GNS>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, z);
+  igemm_epilogue<MI, NI, GNS>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, zo, zr);
   if (STAMP) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
 }
 
@@ -512,6 +514,10 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     LBMK_REQUIRE(!d.residual && !d.rowvec && !d.out_f32, "igemm: GEGLU epilogue is bias-only, bf16");
   }
   if ((d.so % 4) || (d.sr % 4)) LBMK_REQUIRE(false, "igemm: so/sr must be multiples of 4");
+  if (d.batch_inner > 1) {
+    LBMK_REQUIRE(d.batch % d.batch_inner == 0 && d.sa2 % 8 == 0 && d.sw2 % 8 == 0 && d.so2 % 4 == 0 && !d.residual,
+                 "igemm: inner batch %d of %d / inner strides", d.batch_inner, d.batch);
+  }
   const bool gn = d.gn_partial != nullptr;
   if (gn) {
     LBMK_REQUIRE(lbmk_igemm_gn_partial_floats(d.M, d.N, d.Cin, d.OH, d.OW, d.gn_groups) > 0,

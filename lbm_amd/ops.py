@@ -257,16 +257,20 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 1.0,
             bias_m: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
             residual: Optional[torch.Tensor] = None, tile: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Batched out[z] = alpha * a[z] @ b[z]^T.  a: bf16 [Z, M, K] or [M, K]; b: bf16 [Z, N, K] or
-    [N, K]; rows contiguous, K a multiple of 64.  bias_m: f32 [M] per output row; bias_n: f32 [N].
-    ``out``: optional preallocated [Z, M, N] / [M, N] view (unit column stride; row and batch strides free)."""
+    """Batched out[z] = alpha * a[z] @ b[z]^T.  a: bf16 [M, K], [Z, M, K] or [Z1, Z2, M, K]; b likewise with N
+    rows; unit stride along K, every other stride free (multiples of 8), so per-head views of a
+    [B, N, H*D] tensor batch over (image, head) in one launch.  K a multiple of 8.
+    bias_m: f32 [M] per output row; bias_n: f32 [N].
+    ``out``: optional preallocated view of the result shape (unit column stride; other strides free)."""
     _need_gpu(a, b)
     assert a.dtype == bf16 and b.dtype == bf16 and a.stride(-1) == 1 and b.stride(-1) == 1
-    Z = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
+    nb = max(a.dim(), b.dim()) - 2
+    assert nb in (0, 1, 2) and a.dim() in (2, nb + 2) and b.dim() in (2, nb + 2)
+    lead = tuple((a if a.dim() == nb + 2 else b).shape[:nb])
     M, K = a.shape[-2], a.shape[-1]
     N = b.shape[-2]
-    assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0
-    shape = (Z, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
+    assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0 and a.stride(-2) % 8 == 0
+    shape = lead + (M, N)
     if out is None:
         out = torch.empty(*shape, dtype=out_dtype, device=a.device)
     else:
@@ -287,10 +291,18 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     d.ldo, d.rowvec_ld = out.stride(-2), 0
     d.ldr = residual.stride(-2) if residual is not None else 0
     d.act, d.out_f32, d.alpha = ACT_NONE, 1 if out_dtype == torch.float32 else 0, alpha
-    d.batch = Z
-    d.sa = a.stride(0) if a.dim() == 3 else 0
-    d.sw = b.stride(0) if b.dim() == 3 else 0
-    d.so = out.stride(0) if len(shape) == 3 else 0
+    full_a, full_b = a.dim() == nb + 2, b.dim() == nb + 2
+    if nb == 2:
+        d.batch, d.batch_inner = lead[0] * lead[1], lead[1]
+        d.sa, d.sa2 = (a.stride(0), a.stride(1)) if full_a else (0, 0)
+        d.sw, d.sw2 = (b.stride(0), b.stride(1)) if full_b else (0, 0)
+        d.so, d.so2 = out.stride(0), out.stride(1)
+        assert residual is None
+    else:
+        d.batch = lead[0] if nb == 1 else 1
+        d.sa = a.stride(0) if (nb == 1 and full_a) else 0
+        d.sw = b.stride(0) if (nb == 1 and full_b) else 0
+        d.so = out.stride(0) if nb == 1 else 0
     d.sr = residual.stride(0) if (residual is not None and residual.dim() == 3) else 0
     d.tile = tile
     _igemm(d)
