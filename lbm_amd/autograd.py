@@ -41,7 +41,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dy2, ctx.mod.packed_t())[:, :K].reshape(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=torch.float32)[:N, :K].to(weight.dtype)
+            dw = ops.gemm_tn(dy2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=weight.dtype)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy2)[0].to(weight.dtype)
         if ctx.has_res and ctx.needs_input_grad[3]:

@@ -619,7 +619,7 @@ extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
 
 extern "C" int64_t lbmk_layernorm_bwd_scratch_floats(int rows, int C) {
   if (rows <= 0 || C <= 0 || C % 8 || C > 2048) return -1;
-  int nblk = (rows + 63) / 64;
+  int nblk = (rows + 15) / 16;       // 4 rows per wave: enough workgroups to fill the chip at a few thousand rows
   if (nblk > 1024) nblk = 1024;
   return (int64_t)nblk * 2 * C;
 }

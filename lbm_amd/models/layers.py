@@ -88,7 +88,13 @@ class HipLinear(nn.Linear, _Cached):
 
     def packed_t(self) -> ops.PackedWeight:
         """W^T as a packed [K, N] layer: dX = dY . W is the forward GEMM on it"""
-        return self._cached("t", (self.weight,), lambda: ops.pack_linear_weight(self.weight.t().contiguous(), None))
+        def build():
+            w = self.weight.detach()
+            n, k = w.shape
+            if w.is_cuda and w.dtype == torch.bfloat16 and w.is_contiguous() and n % 8 == 0 and k % 8 == 0:
+                return ops.pack_linear_weight(ops.transpose(w), None)       # one kernel, result aliases as the pack
+            return ops.pack_linear_weight(w.t().contiguous(), None)
+        return self._cached("t", (self.weight,), build)
 
     def forward(self, x, *, residual=None, rowvec=None, rows_per_image=0, act=ops.ACT_NONE, geglu=False, out=None):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):

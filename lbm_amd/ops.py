@@ -92,10 +92,15 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pa
     """[N, K] -> bf16 [N, Kp] (K padded to a multiple of 64 with zeros)."""
     N, K = weight.shape
     k8 = ceil_to(K, 8)
+    b = None if bias is None else bias.detach().float().contiguous()
+    w = weight.detach()
+    if K == k8 and w.dtype == bf16 and w.is_contiguous() and w.data_ptr() % 16 == 0:
+        # already the kernel's layout: alias the parameter (the K tail of the last 64-deep tile is masked
+        # by the kernel), so an optimizer step needs no re-pack
+        return PackedWeight(w, b, N, k8, k8, k8, 1, 1, alg_nk=N * K)
     Kp = ceil_to(k8, 64)
     packed = torch.zeros(N, Kp, dtype=bf16, device=weight.device)
-    packed[:, :K] = weight.detach().to(bf16)
-    b = None if bias is None else bias.detach().float().contiguous()
+    packed[:, :K] = w.to(bf16)
     return PackedWeight(packed, b, N, k8, Kp, k8, 1, 1, alg_nk=N * K)
 
 
