@@ -174,7 +174,15 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, q, k, v, heads, dim_head, scale):
         if k.shape[1] % 8 or q.shape[1] % 8:
             raise NotImplementedError("training attention needs token counts that are multiples of 8")
-        o = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale)
+        if dim_head in (40, 64, 80, 160):
+            o = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale)
+        else:
+            # head dims without a flash kernel (VAE mid block: one head of 512): materialised scores
+            B, Nq, C = q.shape
+            p = ops.softmax_rows(ops.gemm_nt(_heads(q, heads, dim_head), _heads(k, heads, dim_head),
+                                             out_dtype=torch.float32, alpha=scale))
+            o = torch.empty_like(q)
+            ops.gemm_nt(p, ops.transpose(v).view(B, heads, dim_head, k.shape[1]), out=_heads(o, heads, dim_head))
         ctx.save_for_backward(q, k, v)
         ctx.cfg = (heads, dim_head, scale)
         return o
@@ -242,3 +250,47 @@ class LatentLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         pred, z_src, z, mask = ctx.saved_tensors
         return ops.latent_loss_bwd(pred, z_src, z, mask if ctx.has_mask else None, gout, ctx.l1), None, None, None, None
+
+
+class PixelLossFn(torch.autograd.Function):
+    """per-sample mean of ((clamp(dec, -1, 1) - target) * mask)^2 or |.| (lbm_model.py:197-249, l2 / l1)."""
+
+    @staticmethod
+    def forward(ctx, dec, target, mask, l1):
+        dec, target = dec.contiguous(), target.contiguous()
+        ctx.save_for_backward(dec, target, mask if mask is not None else torch.empty(0))
+        ctx.l1, ctx.has_mask = l1, mask is not None
+        return ops.pixel_loss(dec, target, mask, l1=l1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        dec, target, mask = ctx.saved_tensors
+        return ops.pixel_loss_bwd(dec, target, mask if ctx.has_mask else None, gout, ctx.l1), None, None, None
+
+
+class AxpyRowsFn(torch.autograd.Function):
+    """x[b] + a[b] * y[b] in f32, differentiable in y (predicted x0 = x_t - sigma * prediction)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a):
+        ctx.save_for_backward(a)
+        ctx.ydt = y.dtype
+        return ops.axpy_rows(x.contiguous(), y.contiguous(), a)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        return None, ops.scale_rows(g.contiguous(), a).to(ctx.ydt), None
+
+
+class ScaleShiftFn(torch.autograd.Function):
+    """y = x * a + b elementwise on bf16 (latent un-scaling ahead of the VAE decoder)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.a = a
+        return ops.scale_shift(x, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.scale_shift(g.contiguous(), ctx.a, 0.0), None, None

@@ -66,8 +66,9 @@ class LBMModel(BaseModel):
     def forward(self, batch: Dict[str, Any], step=0, batch_idx=0, *args, bridge_eps: Optional[torch.Tensor] = None,
                 timesteps: Optional[torch.Tensor] = None, **kwargs):
         self.num_iterations += 1
-        if self.pixel_loss_weight > 0:
-            raise NotImplementedError("pixel loss (VAE decode backward / LPIPS) is not implemented on the HIP path")
+        if self.pixel_loss_weight > 0 and self.pixel_loss_type == "lpips":
+            raise NotImplementedError("the LPIPS pixel loss needs the lpips package's VGG weights, which are not available offline; "
+                                      "pixel_loss_type 'l2' / 'l1' run on the HIP path")
 
         if self.vae is not None:
             z = self.vae.encode(batch[self.target_key])
@@ -78,10 +79,12 @@ class LBMModel(BaseModel):
 
         if self.mask_key in batch:
             valid_mask = batch[self.mask_key].bool()[:, 0, :, :].unsqueeze(1)
+            valid_mask_pixels = valid_mask
             valid_mask_for_latent = ~torch.max_pool2d((~valid_mask).float(), downsampling_factor, downsampling_factor).bool()
             valid_mask_for_latent = valid_mask_for_latent.repeat((1, z.shape[1], 1, 1))
         else:
             valid_mask_for_latent = None          # all valid
+            valid_mask_pixels = None
 
         source_image = batch[self.source_key]
         z_source = self.vae.encode(source_image) if self.vae is not None else source_image
@@ -121,7 +124,16 @@ class LBMModel(BaseModel):
         else:
             loss = torch.zeros(z.shape[0], device=z.device)
             latent_recon_loss = torch.zeros_like(loss)
-        pixel_loss = torch.zeros_like(latent_recon_loss)
+        if self.pixel_loss_weight > 0:
+            if prediction.requires_grad:
+                from ...autograd import AxpyRowsFn
+                x0 = AxpyRowsFn.apply(noisy_sample, prediction, neg_sig)
+            else:
+                x0 = denoised_sample
+            pixel_loss = self.pixel_loss(x0, batch[self.target_key].detach(), valid_mask_pixels)
+            loss = loss + self.pixel_loss_weight * pixel_loss
+        else:
+            pixel_loss = torch.zeros_like(latent_recon_loss)
 
         return {"loss": loss.mean(), "latent_recon_loss": latent_recon_loss, "pixel_recon_loss": pixel_loss.mean(),
                 "predicted_hr": denoised_sample, "noisy_sample": noisy_sample}
@@ -133,6 +145,34 @@ class LBMModel(BaseModel):
         zeros = torch.zeros_like(model_input)
         return ops.latent_loss(prediction.contiguous(), model_input.contiguous(), zeros, valid_latent_mask,
                                l1=self.latent_loss_type == "l1")
+
+    def pixel_loss(self, prediction, model_input, valid_mask, offsets=None):
+        """Random crop to ``pixel_loss_max_size``, decode, clamp, l2 / l1 against the target pixels
+        (lbm_model.py:197-249; crop offsets are drawn on the host in the reference's order).
+        ``offsets=(offset_h, offset_w)`` overrides the draw (tests)."""
+        f = self.vae.downsampling_factor if self.vae is not None else 1
+        latent_crop, input_crop = self.pixel_loss_max_size // f, self.pixel_loss_max_size
+        crop_h = max(prediction.shape[2] - latent_crop, 0)
+        crop_w = max(prediction.shape[3] - latent_crop, 0)
+        input_crop_h = max(model_input.shape[2] - input_crop, 0)
+        input_crop_w = max(model_input.shape[3] - input_crop, 0)
+        offset_h = 0 if crop_h == 0 else int(torch.randint(0, crop_h, (1,)).item())
+        offset_w = 0 if crop_w == 0 else int(torch.randint(0, crop_w, (1,)).item())
+        if offsets is not None:
+            offset_h, offset_w = offsets
+        ioh, iow = offset_h * f, offset_w * f
+        prediction = prediction[:, :, crop_h - offset_h: min(crop_h - offset_h + latent_crop, prediction.shape[2]),
+                                crop_w - offset_w: min(crop_w - offset_w + latent_crop, prediction.shape[3])]
+        sl_h = slice(input_crop_h - ioh, min(input_crop_h - ioh + input_crop, model_input.shape[2]))
+        sl_w = slice(input_crop_w - iow, min(input_crop_w - iow + input_crop, model_input.shape[3]))
+        model_input = model_input[:, :, sl_h, sl_w].contiguous()
+        if valid_mask is not None:
+            valid_mask = valid_mask[:, :, sl_h, sl_w]
+        decoded = self.vae.decode(prediction) if self.vae is not None else prediction
+        if self.pixel_loss_type not in ("l2", "l1"):
+            raise NotImplementedError(f"pixel loss type {self.pixel_loss_type} is not available on the HIP path")
+        from ...autograd import PixelLossFn
+        return PixelLossFn.apply(decoded.contiguous(), model_input, valid_mask, self.pixel_loss_type == "l1")
 
     def _get_conditioning(self, batch: Dict[str, Any], ucg_keys: List[str] = None, set_ucg_rate_zero=False, *args, **kwargs):
         if self.conditioner is not None:

@@ -56,6 +56,15 @@ class AutoencoderKLDiffusers(BaseModel):
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         if self.has_latents_mean and self.has_latents_std:
             raise NotImplementedError("latents_mean / latents_std un-scaling is not implemented (absent from the SD / SDXL VAE configs)")
+        if torch.is_grad_enabled() and z.requires_grad:
+            # differentiable route (pixel loss): gradients flow to the latent through the frozen decoder
+            from ...autograd import NchwToNhwcFn, NhwcToNchwFn, ScaleShiftFn
+            if z.shape[2] > self.tiling_size[0] or z.shape[3] > self.tiling_size[1]:
+                raise NotImplementedError("tiled decode has no backward; crop the latent to the tile size (pixel_loss_max_size)")
+            zs = ScaleShiftFn.apply(z.contiguous().to(torch.bfloat16), 1.0 / float(self.vae_model.config.scaling_factor),
+                                    float(self.shift_factor))
+            img = self.vae_model.decode_nhwc(NchwToNhwcFn.apply(zs))
+            return NhwcToNchwFn.apply(img, self.vae_model.config.out_channels, z.dtype)
         zc = z.contiguous()
         if zc.dtype != torch.bfloat16:
             zc = zc.to(torch.bfloat16)

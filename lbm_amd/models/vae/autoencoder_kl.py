@@ -47,6 +47,10 @@ class VaeAttention(nn.Module, _Cached):
         if N % 8:
             raise ValueError(f"VAE attention needs H*W % 8 == 0 (got {H}x{W})")
         xn = self.group_norm(x).view(B, N, C)
+        if torch.is_grad_enabled() and x.requires_grad:
+            from ...autograd import AttentionFn
+            o = AttentionFn.apply(self.to_q(xn), self.to_k(xn), self.to_v(xn), 1, C, 1.0 / math.sqrt(C))
+            return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
         q = self.to_q(xn)
         k = self.to_k(xn)
         wv, bv = self._v_weight()

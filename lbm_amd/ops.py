@@ -741,3 +741,34 @@ def adamw_step(p_flat, g_flat, m, v, *, lr: float, betas=(0.9, 0.999), eps: floa
     assert p_flat.is_contiguous() and g_flat.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     check(lib.lbmk_adamw(p_flat.data_ptr(), g_flat.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, betas[0], betas[1], eps,
                          weight_decay, step, grad_scale, _stream()), "lbmk_adamw")
+
+
+def _mask_u8(mask, like):
+    return None if mask is None else mask.to(torch.uint8).expand_as(like).contiguous()
+
+
+def pixel_loss(dec, target, mask=None, l1: bool = False):
+    """per-sample mean of ((clamp(dec, -1, 1) - target) * mask)^2 or |.| -> f32 [B]"""
+    _need_gpu(dec, target, mask)
+    assert dec.shape == target.shape and dec.is_contiguous() and target.is_contiguous()
+    B = dec.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=dec.device)
+    check(lib.lbmk_pixel_loss(dec.data_ptr(), target.data_ptr(), _ptr(_mask_u8(mask, dec)), out.data_ptr(), B,
+                              dec[0].numel(), 1 if l1 else 0, _dt(dec), _dt(target), _stream()), "lbmk_pixel_loss")
+    return out
+
+
+def pixel_loss_bwd(dec, target, mask, gout, l1: bool):
+    _need_gpu(dec, target, gout)
+    B = dec.shape[0]
+    gout = gout.reshape(B).float().contiguous()
+    ddec = torch.empty_like(dec)
+    check(lib.lbmk_pixel_loss_bwd(dec.data_ptr(), target.data_ptr(), _ptr(_mask_u8(mask, dec)), gout.data_ptr(),
+                                  ddec.data_ptr(), B, dec[0].numel(), 1 if l1 else 0, _dt(dec), _dt(target), _stream()),
+          "lbmk_pixel_loss_bwd")
+    return ddec
+
+
+def scale_rows(y, a):
+    """out[b] = a[b] * y[b] in f32 (a: f32 [B])"""
+    return axpy_rows(torch.zeros_like(y), y, a)

@@ -345,3 +345,53 @@ def test_training_pipeline_reduces_loss(cuda):
     grp = pipe.optims[0].groups[0]
     lo, hi = grp.flat.data_ptr(), grp.flat.data_ptr() + grp.flat.numel() * 2
     assert all(lo <= p.data_ptr() < hi for p in grp.params)
+
+
+def test_pixel_loss_through_vae_decoder(cuda):
+    """pixel loss (l2): gradient w.r.t. the latent through the frozen VAE decoder (incl. the single-head
+    d=512 mid attention) against fp32 autograd through the oracle decoder."""
+    from lbm_amd.autograd import PixelLossFn
+    from lbm_amd.models.vae import AutoencoderKL, AutoencoderKLDiffusers, AutoencoderKLDiffusersConfig
+    from oracle import diffusers_ref as dr
+    torch.manual_seed(1)
+    core = AutoencoderKL(scaling_factor=0.13025).to(BF)
+    sd = {k: v.detach().float().cpu() for k, v in core.state_dict().items()}
+    vae = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version="unused", tiling_size=(128, 128)), vae_model=core).to(cuda)
+    vae.freeze()
+    g = torch.Generator().manual_seed(2)
+    B, L = 2, 16
+    z = (torch.randn(B, 4, L, L, generator=g) * 0.5).to(BF)
+    tgt = (torch.rand(B, 3, 8 * L, 8 * L, generator=g) * 2 - 1).to(BF)
+    zr = z.float().requires_grad_()
+    dec_r = dr.vae_decode(sd, zr / 0.13025).clamp(-1, 1)
+    per_r = ((dec_r - tgt.float()) ** 2).mean(dim=(1, 2, 3))
+    per_r.sum().backward()
+    zg = z.to(cuda).float().requires_grad_()
+    dec = vae.decode(zg)
+    per = PixelLossFn.apply(dec, tgt.to(cuda), None, False)
+    assert rel_l2(per, per_r) < 2e-2
+    per.sum().backward()
+    assert zg.grad is not None and rel_l2(zg.grad, zr.grad) < 6e-2
+    cos = float((zg.grad.cpu().double() * zr.grad.double()).sum() / (zg.grad.cpu().double().norm() * zr.grad.double().norm()))
+    assert cos > 0.995
+
+
+def test_lbm_forward_with_pixel_loss(cuda):
+    """LBMModel.forward with pixel_loss_weight > 0 (l1): finite loss, gradients reach the denoiser."""
+    from lbm_amd.models.vae import AutoencoderKL, AutoencoderKLDiffusers, AutoencoderKLDiffusersConfig
+    model = _toy_lbm(cuda)
+    torch.manual_seed(1)
+    core = AutoencoderKL(scaling_factor=0.13025).to(BF)
+    model.vae = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version="unused", tiling_size=(128, 128)), vae_model=core).to(cuda)
+    model.vae.freeze()
+    model.pixel_loss_weight, model.pixel_loss_type, model.pixel_loss_max_size = 10.0, "l1", 64
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    imgs = {k: (torch.rand(2, 3, 128, 128, generator=g) * 2 - 1).to(BF).to(cuda) for k in ("target", "source")}
+    out = model(imgs, timesteps=torch.tensor([500, 250], device=cuda))
+    assert float(out["pixel_recon_loss"].detach()) > 0 and torch.isfinite(out["loss"].detach())
+    assert float(out["loss"].detach()) > float(out["latent_recon_loss"].detach())
+    out["loss"].backward()
+    grads = [p.grad for p in model.denoiser.parameters()]
+    assert all(gd is not None and torch.isfinite(gd.float()).all() for gd in grads)
+    assert all(p.grad is None for p in model.vae.parameters())
