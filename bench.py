@@ -147,7 +147,7 @@ def main():
     if rank == 0:
         total_images = args.batch * world * args.steps
         line = {
-            "metric": "images/sec (1024^2, 1-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
+            "metric": f"images/sec ({args.res}^2, {args.nfe}-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "ms_per_image": round(elapsed / total_images * 1e3 * world, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

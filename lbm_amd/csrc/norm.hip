@@ -4,7 +4,7 @@
 // image.  Three launches: (1) per-slab partial sums, every thread owning one fixed 8-channel
 // chunk and striding over rows with 16-byte loads; (2) a tiny deterministic reduction of the
 // slab partials into mean / rstd; (3) apply y = x*a[c] + b[c] (+SiLU) with the same mapping.
-// No float atomics reach global memory, so results are bitwise reproducible.
+// No float atomics anywhere (LDS included): every sum has a fixed order, results are bit-reproducible.
 #include "common.h"
 
 namespace {
@@ -41,14 +41,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                                                        float* __restrict__ partial, int HW, int C,
                                                        int G, int nch, int rpp, int rows_per_slab,
                                                        int nslab) {
-  __shared__ float gs[64];   // [group in segment][sum, sumsq] (<= 32 groups)
+  // fixed-order reduction (no float atomics anywhere: results are bit-reproducible run to run)
+  __shared__ float sums[2][256 * 8];   // [sum | sumsq][row lane][channel of the segment]
+  __shared__ float chs[2][2048];       // per-channel totals of this block
   const int t = threadIdx.x;
   const int slab = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
   const int cpg = C / G;
   const int gps = G / gridDim.y;     // groups per segment
   const int cseg = nch * 8;          // channels per segment
-  if (t < 64) gs[t] = 0.f;
-  __syncthreads();
   const int chunk = t % nch, rl = t / nch;
   float s[8], ss[8];
 #pragma unroll
@@ -75,27 +75,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       accum(v0); accum(v1); accum(v2); accum(v3);
     }
     for (; r < r1; r += rpp) accum(*(const u16x8*)(base + (int64_t)r * C));
-    // fold the 8 channels into their groups (consecutive channels share a group)
-    int gprev = (chunk * 8) / cpg;
-    float as = 0.f, ass = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int g = (chunk * 8 + e) / cpg;
-      if (g != gprev) {
-        atomicAdd(&gs[gprev * 2], as);
-        atomicAdd(&gs[gprev * 2 + 1], ass);
-        as = 0.f; ass = 0.f; gprev = g;
-      }
-      as += s[e];
-      ass += ss[e];
+      sums[0][rl * cseg + chunk * 8 + e] = s[e];
+      sums[1][rl * cseg + chunk * 8 + e] = ss[e];
     }
-    atomicAdd(&gs[gprev * 2], as);
-    atomicAdd(&gs[gprev * 2 + 1], ass);
   }
   __syncthreads();
+  // per channel: row lanes in order
+  for (int c = t; c < cseg; c += 256) {
+    float a = 0.f, a2 = 0.f;
+    for (int r = 0; r < rpp; ++r) { a += sums[0][r * cseg + c]; a2 += sums[1][r * cseg + c]; }
+    chs[0][c] = a;
+    chs[1][c] = a2;
+  }
+  __syncthreads();
+  // per group: its channels in order
   if (t < gps * 2) {
-    const int g = seg * gps + (t >> 1);
-    partial[(((int64_t)b * G + g) * nslab + slab) * 2 + (t & 1)] = gs[t];
+    const int gl = t >> 1, which = t & 1;
+    float a = 0.f;
+    for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) a += chs[which][c];
+    const int g = seg * gps + gl;
+    partial[(((int64_t)b * G + g) * nslab + slab) * 2 + which] = a;
   }
 }
 

@@ -235,8 +235,10 @@ class LBMModel(BaseModel):
         n = len(sched.timesteps)
         for i, t in enumerate(sched.timesteps):
             denoiser_input = sched.scale_model_input(sample, t) if hasattr(sched, "scale_model_input") else sample
-            pred = self.denoiser(sample=denoiser_input, timestep=t.to(z.device).repeat(denoiser_input.shape[0]),
-                                 conditioning=conditioning)
+            # the timestep vector is filled on the device from the host scalar: no host-to-device copy in the
+            # loop, so the whole call can be captured into a HIP graph
+            t_vec = torch.full((denoiser_input.shape[0],), float(t), dtype=sched.timesteps.dtype, device=z.device)
+            pred = self.denoiser(sample=denoiser_input, timestep=t_vec, conditioning=conditioning)
             last = i == n - 1
             eps = None
             if not last:

@@ -299,3 +299,22 @@ def test_unet_sdxl_style_full_size(cuda):
     with torch.no_grad():
         out = m(sample=x.to(cuda), timestep=ts.to(cuda), conditioning={"cond": {}})
     assert rel_l2(out, ref) < 1e-2
+
+
+def test_inference_is_bit_reproducible(small_unet, vae, cuda):
+    """no kernel on the inference path accumulates in a scheduling-dependent order (no float atomics):
+    the same inputs give bit-identical latents and images run to run"""
+    m, _ = small_unet
+    w, _ = vae
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 4, 32, 32, generator=g).to(BF).to(cuda)
+    ts = torch.full((2,), 500.0, device=cuda)
+    img = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(BF).to(cuda)
+    eps = torch.randn(2, 4, 8, 8, generator=g).to(BF).to(cuda)
+    with torch.no_grad():
+        outs = [m(sample=x, timestep=ts, conditioning={"cond": {}}) for _ in range(3)]
+        zs = [w.encode(img, eps=eps) for _ in range(3)]
+        ds = [w.decode(zs[0]) for _ in range(3)]
+    assert all(torch.equal(outs[0], o) for o in outs)
+    assert all(torch.equal(zs[0], z) for z in zs)
+    assert all(torch.equal(ds[0], d) for d in ds)
