@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int AI = BM / RPP;                  // LDS-DMA loads per thread for the A tile
-  constexpr int BI = (BN >= RPP) ? BN / RPP : 1;
+  constexpr int BI = (BN + RPP - 1) / RPP;      // LDS-DMA loads per thread for the B tile (last one partial when BN % RPP != 0)
   constexpr int STAGE = (BM + BN) * 128;        // bytes of one K-tile (64 deep) of both operands
   static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % RPP == 0, "tile shape");
   // all LDS in ONE array: a second __shared__ object makes hipcc drain vmcnt before every ds_read
@@ -241,7 +241,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   const int ohw = p.OH * p.OW;
   const int IHe = p.up2 ? 2 * p.IH : p.IH;
   const int IWe = p.up2 ? 2 * p.IW : p.IW;
-  const bool b_loader = (BN >= RPP) || (t < BN * 8);
   const int ntaps = p.KH * p.KW;
   // Cin % 64 == 0: all lanes of a K-tile sit on the same filter tap, so (tap, channel base) is scalar
   constexpr bool uni = FAST;
@@ -368,12 +367,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
         while (ch >= p.Cin) { ch -= p.Cin; ++tap; }
       }
     }
-    if (b_loader) {
-      const bool k_ok = (kt << 6) + kk < p.K;
+    const bool k_ok = (kt << 6) + kk < p.K;
 #pragma unroll
-      for (int i = 0; i < BI; ++i) {
+    for (int i = 0; i < BI; ++i) {
+      // a wave stages 8 consecutive rows; waves whose rows lie past the tile (wave-uniform) skip the load
+      if ((BN % RPP == 0) || wave * 8 + RPP * i < BN)
         buffer_lds16(W, w_bytes, k_ok ? w_vo[i] : OOB, kt << 7, buf + BM * 128 + (wave * 8 + RPP * i) * 128);
-      }
     }
   };
 
@@ -447,7 +446,8 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {256, 256},    // 7: 256x256 with 16 waves (64x64 per wave)
                           {512, 128},    // 8: 16 waves, for N = 128 layers
                           {256, 128},    // 9: 16 waves (64x32 per wave)
-                          {256, 128}};   // 10: 8 waves, single-buffered, two workgroups per CU
+                          {256, 128},    // 10: 8 waves, single-buffered, two workgroups per CU
+                          {256, 160}};   // 11: 16 waves (32x80 per wave): the UNet widths 320 ... 2560 are multiples of 160
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
@@ -534,20 +534,22 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       // Cost model over the production tiles.  A tile shape keeps `resident` workgroups on a CU and
       // then sustains `rate` (measured, TFLOP/s at full occupancy, mid-size K); padded rows / columns
       // are paid in full.  One-per-CU tiles run in whole rounds of the CU count; co-resident tiles
-      // drain smoothly (a CU with fewer workgroups left runs them faster), so their round count is
-      // fractional, floored at half a round.
+      // drain more smoothly (a CU with fewer workgroups left runs them faster): their round count is
+      // whole workgroups per CU divided by the residency, floored at half a round.
       struct Cand { int tile, bm, bn, resident; float rate; };
-      static const Cand cands[] = {{7, 256, 256, 1, 1300.f}, {8, 512, 128, 1, 1150.f}, {10, 256, 128, 2, 1170.f},
-                                   {0, 128, 128, 4, 1130.f}, {1, 128, 64, 4, 920.f},   {3, 64, 64, 8, 750.f}};
+      static const Cand cands[] = {{7, 256, 256, 1, 1300.f}, {11, 256, 160, 1, 1200.f}, {8, 512, 128, 1, 1150.f},
+                                   {10, 256, 128, 2, 1170.f}, {0, 128, 128, 4, 1130.f}, {1, 128, 64, 4, 920.f},
+                                   {3, 64, 64, 8, 750.f}};
       const int cus = lbmk_num_cus();
       double best = 1e300;
       tile = 0;
       for (const Cand& c : cands) {
-        if (gn && (c.tile == 1 || c.tile == 3)) continue;   // statistics strips are 64 rows x 64 columns per wave
-        const double blocks = (double)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
-        const double slots = (double)cus * c.resident;
-        double rounds = blocks / slots;
-        if (c.resident == 1) rounds = (double)(long)((blocks + slots - 1) / slots);
+        if (gn && (c.tile == 1 || c.tile == 3 || c.tile == 11)) continue;   // statistics strips are 64 rows x 64 columns per wave
+        if (d.act == LBMK_ACT_GEGLU && c.tile == 11) continue;              // odd number of column groups per wave
+        const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
+        const long per_cu = (blocks + cus - 1) / cus;
+        double rounds = (double)per_cu / c.resident;
+        if (c.resident == 1) rounds = (double)per_cu;
         else if (rounds < 0.5) rounds = 0.5;
         const double cost = rounds * c.resident * c.bm * c.bn / c.rate;
         if (cost < best) { best = cost; tile = c.tile; }
@@ -557,7 +559,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 115) { launch<512, 128, 8, 2, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
-  if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2, "igemm: GEGLU needs a tile with >= 32 columns per wave");
+  if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
   if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10, "igemm: tile %d has no 64x64 wave strips", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
@@ -572,6 +574,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 8: launch<512, 128, 8, 2, true>(d, s); break;
     case 9: launch<256, 128, 4, 4, true>(d, s); break;
     case 10: launch<256, 128, 4, 2, false, false, 2>(d, s); break;
+    case 11: launch<256, 160, 8, 2, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
