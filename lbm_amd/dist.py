@@ -17,8 +17,11 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: str, device: Optional[torch.device] = None):
     """Initialises the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
     rank, _, world = env_world()
-    if world <= 1:
+    if world <= 1 and os.environ.get("LBM_FORCE_DIST") != "1":     # LBM_FORCE_DIST=1: a one-rank group, to exercise the collectives
         return None
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
     import torch.distributed as dist
     if not dist.is_initialized():
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
