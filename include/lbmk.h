@@ -111,7 +111,7 @@ int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta
  *   k  : bf16 [B][Nk][ldk] likewise
  *   vt : bf16 [B][H*D][ldvt]  (V transposed: row = channel, column = key)
  *   o  : bf16 [B][Nq][ldo]
- * Supported D: 40, 64, 80, 160; keys at or past Nk are masked, ldvt >= Nk rounded up to 8.
+ * Supported D: 8, 16, 32, 40, 64, 80, 160; keys at or past Nk are masked, ldvt >= Nk rounded up to 8.
  * ---------------------------------------------------------------------- */
 int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         int B, int H, int Nq, int Nk, int D,

@@ -383,8 +383,8 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
                                    int ldo, int64_t sq, int64_t sk, int64_t svt, int64_t so,
                                    float scale, void* stream) {
   LBMK_REQUIRE(q && k && vt && o, "flash_attn: null pointer");
-  LBMK_REQUIRE(Dh == 64 || Dh == 40 || Dh == 80 || Dh == 160,
-               "flash_attn: head_dim %d not supported (40, 64, 80, 160)", Dh);
+  LBMK_REQUIRE(Dh == 64 || Dh == 40 || Dh == 80 || Dh == 160 || Dh == 8 || Dh == 16 || Dh == 32,
+               "flash_attn: head_dim %d not supported (8, 16, 32, 40, 64, 80, 160)", Dh);
   LBMK_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && B <= 65535 && H <= 65535, "flash_attn: sizes");
   LBMK_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "flash_attn: leading dims");
   LBMK_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && svt % 8 == 0 && so % 4 == 0, "flash_attn: batch strides");
@@ -399,6 +399,9 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
 #define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2
   switch (Dh) {
     case 64: hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 8: hipLaunchKernelGGL(flash_fwd_gen_kernel<8>, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 16: hipLaunchKernelGGL(flash_fwd_gen_kernel<16>, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 32: hipLaunchKernelGGL(flash_fwd_gen_kernel<32>, grid, dim3(256), 0, s, FA_ARGS); break;
     case 40: hipLaunchKernelGGL(flash_fwd_gen_kernel<40>, grid, dim3(256), 0, s, FA_ARGS); break;
     case 80: hipLaunchKernelGGL(flash_fwd_gen_kernel<80>, grid, dim3(256), 0, s, FA_ARGS); break;
     case 160: hipLaunchKernelGGL(flash_fwd_gen_kernel<160>, grid, dim3(256), 0, s, FA_ARGS); break;

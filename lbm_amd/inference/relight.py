@@ -147,7 +147,54 @@ def build_filllight_model(backbone_signature: str = "stable-diffusion-v1-5/stabl
     return _build_relight_model(backbone_signature=backbone_signature, **kwargs)
 
 
-def build_filllight_refine_model(*args, **kwargs) -> LBMModel:
-    raise NotImplementedError(
-        "the pixel-space refine model (diffusers UNet2DModel [64,128,256,256] without a VAE, relight.py:325-417) "
-        "is not on the HIP path yet")
+def build_filllight_refine_model(
+        backbone_signature: str = "stable-diffusion-v1-5/stable-diffusion-v1-5",
+        unet_input_channels: int = 6,
+        unet_output_channels: int = 3,
+        block_out_channels: Optional[List[int]] = None,
+        layers_per_block: int = 2,
+        timestep_sampling: str = "log_normal",
+        selected_timesteps: Optional[List[float]] = None,
+        prob: Optional[List[float]] = None,
+        conditioning_images_keys: Optional[List[str]] = None,
+        conditioning_masks_keys: Optional[List[str]] = None,
+        source_key: str = "source",
+        target_key: str = "target",
+        mask_key: Optional[str] = None,
+        bridge_noise_sigma: float = 0.0,
+        logit_mean: float = 0.0,
+        logit_std: float = 1.0,
+        pixel_loss_type: str = "lpips",
+        pixel_loss_weight: float = 1.0,
+        latent_loss_type: str = "l2",
+        latent_loss_weight: float = 1.0,
+) -> LBMModel:
+    """Pixel-space refine model (relight.py:325-417): UNet2DModel [64, 128, 256, 256] on 6-channel inputs
+    (bridge sample + raw rgb conditioning), no VAE."""
+    from ..models.unets import DiffusersUNet2DWrapper
+    if conditioning_images_keys is None:
+        conditioning_images_keys = ["rgb"]
+    if conditioning_masks_keys is None:
+        conditioning_masks_keys = []
+    if block_out_channels is None:
+        block_out_channels = [64, 128, 256, 256]
+    denoiser = DiffusersUNet2DWrapper(
+        in_channels=unet_input_channels, out_channels=unet_output_channels,
+        down_block_types=["DownBlock2D"] * len(block_out_channels), up_block_types=["UpBlock2D"] * len(block_out_channels),
+        block_out_channels=block_out_channels, layers_per_block=layers_per_block, norm_num_groups=32, act_fn="silu",
+        center_input_sample=False).to(torch.bfloat16)
+    conditioners = []
+    if conditioning_images_keys or conditioning_masks_keys:
+        emb = RawConcatEmbedder(LatentsConcatEmbedderConfig(image_keys=conditioning_images_keys, mask_keys=conditioning_masks_keys))
+        emb.freeze()
+        conditioners.append(emb)
+    config = LBMConfig(
+        ucg_keys=None, source_key=source_key, target_key=target_key, mask_key=mask_key,
+        latent_loss_weight=latent_loss_weight, latent_loss_type=latent_loss_type, pixel_loss_type=pixel_loss_type,
+        pixel_loss_weight=pixel_loss_weight, timestep_sampling=timestep_sampling, logit_mean=logit_mean, logit_std=logit_std,
+        selected_timesteps=selected_timesteps, prob=prob, bridge_noise_sigma=bridge_noise_sigma)
+    return LBMModel(
+        config, denoiser=denoiser,
+        training_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
+        sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
+        vae=None, conditioner=ConditionerWrapper(conditioners=conditioners)).to(torch.bfloat16)

@@ -24,13 +24,18 @@ VAE_EPS = 1e-6
 _SCORE_BYTES_BUDGET = 2 << 30   # f32 score matrices materialised at once by the mid attention
 
 
-class VaeAttention(nn.Module, _Cached):
-    """Single-head (head_dim = C = 512) self-attention of the VAE mid block, with residual."""
+FLASH_HEAD_DIMS = (8, 16, 32, 40, 64, 80, 160)
 
-    def __init__(self, channels: int, groups: int = 32):
+
+class VaeAttention(nn.Module, _Cached):
+    """Self-attention over a feature map with residual (diffusers' deprecated attention block: group_norm,
+    to_q / to_k / to_v with bias, to_out.0).  The VAE mid block uses one head of C = 512; UNetMidBlock2D of
+    the pixel-space UNet uses C / 8 heads of 8."""
+
+    def __init__(self, channels: int, groups: int = 32, heads: int = 1, eps: float = VAE_EPS):
         super().__init__()
-        self.channels = channels
-        self.group_norm = HipGroupNorm(groups, channels, eps=VAE_EPS)
+        self.channels, self.heads = channels, heads
+        self.group_norm = HipGroupNorm(groups, channels, eps=eps)
         self.to_q = HipLinear(channels, channels)
         self.to_k = HipLinear(channels, channels)
         self.to_v = HipLinear(channels, channels)
@@ -47,10 +52,17 @@ class VaeAttention(nn.Module, _Cached):
         if N % 8:
             raise ValueError(f"VAE attention needs H*W % 8 == 0 (got {H}x{W})")
         xn = self.group_norm(x).view(B, N, C)
-        if torch.is_grad_enabled() and x.requires_grad:
+        D = C // self.heads
+        if torch.is_grad_enabled() and (x.requires_grad or self.to_q.weight.requires_grad):
             from ...autograd import AttentionFn
-            o = AttentionFn.apply(self.to_q(xn), self.to_k(xn), self.to_v(xn), 1, C, 1.0 / math.sqrt(C))
+            o = AttentionFn.apply(self.to_q(xn), self.to_k(xn), self.to_v(xn), self.heads, D, 1.0 / math.sqrt(D))
             return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
+        if D in FLASH_HEAD_DIMS:
+            wv, bv = self._v_weight()
+            o = ops.flash_attn(self.to_q(xn), self.to_k(xn), ops.gemm_nt(wv, xn, bias_m=bv), self.heads, D)
+            return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
+        if self.heads != 1:
+            raise NotImplementedError(f"spatial attention with {self.heads} heads of {D}")
         q = self.to_q(xn)
         k = self.to_k(xn)
         wv, bv = self._v_weight()

@@ -224,6 +224,53 @@ def unet_forward(sd: SD, cfg: dict, sample, timestep, encoder_hidden_states=None
 
 
 # ---------------------------------------------------------------------------------------
+# UNet2DModel (pixel-space refine model, src/lbm/inference/relight.py:356-366)
+# ---------------------------------------------------------------------------------------
+def _spatial_attention(sd: SD, prefix: str, x, heads: int, groups: int, eps: float):
+    """diffusers Attention(residual_connection=True, bias=True, norm_num_groups=groups) on a feature map
+    (the deprecated-attention-block form used by UNetMidBlock2D and the VAE mid block)."""
+    B, C, H, W = x.shape
+    h = group_norm(sd, prefix + ".group_norm", x, groups, eps)
+    tok = h.view(B, C, H * W).transpose(1, 2)
+    o = attention(sd, prefix, tok, None, heads)
+    return o.transpose(1, 2).reshape(B, C, H, W) + x
+
+
+def unet2d_forward(sd: SD, cfg: dict, sample, timestep):
+    """diffusers 0.32.2 UNet2DModel.forward with DownBlock2D / UpBlock2D levels, positional time embedding,
+    UNetMidBlock2D with one self-attention of C / attention_head_dim heads (default head dim 8)."""
+    chans = list(cfg["block_out_channels"])
+    groups, eps = cfg.get("norm_num_groups", 32), cfg.get("norm_eps", 1e-5)
+    lpb = cfg.get("layers_per_block", 2)
+    head_dim = cfg.get("attention_head_dim", 8)
+    t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+    t = t.reshape(-1).float().expand(sample.shape[0]) if t.numel() == 1 else t.reshape(-1).float()
+    temb = linear(sd, "time_embedding.linear_1", timestep_embedding(t, chans[0]))
+    temb = linear(sd, "time_embedding.linear_2", F.silu(temb))
+    h = conv(sd, "conv_in", sample.to(_COMPUTE[-1]))
+    skips = [h]
+    for i in range(len(chans)):
+        for j in range(lpb):
+            h = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", h, temb, groups, eps)
+            skips.append(h)
+        if _has(sd, f"down_blocks.{i}.downsamplers.0.conv.weight"):
+            h = conv(sd, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
+            skips.append(h)
+    h = resnet_block(sd, "mid_block.resnets.0", h, temb, groups, eps)
+    if _has(sd, "mid_block.attentions.0.to_q.weight"):
+        h = _spatial_attention(sd, "mid_block.attentions.0", h, chans[-1] // head_dim, groups, eps)
+    h = resnet_block(sd, "mid_block.resnets.1", h, temb, groups, eps)
+    for i in range(len(chans)):
+        for j in range(lpb + 1):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", h, temb, groups, eps)
+        if _has(sd, f"up_blocks.{i}.upsamplers.0.conv.weight"):
+            h = conv(sd, f"up_blocks.{i}.upsamplers.0.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    h = F.silu(group_norm(sd, "conv_norm_out", h, groups, eps))
+    return conv(sd, "conv_out", h)
+
+
+# ---------------------------------------------------------------------------------------
 # AutoencoderKL
 # ---------------------------------------------------------------------------------------
 VAE_EPS = 1e-6

@@ -415,3 +415,18 @@ def test_conv_fused_groupnorm_stats_ineligible(ops, cuda, gen):
     pw = ops.pack_conv_weight(w.to(cuda), None)
     y = ops.conv2d(x.to(cuda), pw, gn_groups=32)
     assert getattr(y, "_lbmk_gn_partial", None) is None
+
+
+@pytest.mark.parametrize("D,H,N", [(8, 32, 1024), (16, 4, 300), (32, 3, 520)])
+def test_flash_attn_small_head_dims(ops, cuda, gen, D, H, N):
+    """head dims below one 16-deep MFMA step / one 32-row output tile (pixel-space UNet mid block: 32 heads of 8)"""
+    B = 2
+    q, k, v = (randbf(gen, B, N, H * D) for _ in range(3))
+    Np = (N + 7) // 8 * 8
+    vt = torch.zeros(B, H * D, Np, dtype=BF)
+    vt[:, :, :N] = v.transpose(1, 2)
+    o = ops.flash_attn(q.to(cuda), k.to(cuda), vt.to(cuda), H, D)
+    def heads(t):
+        return t.float().view(B, N, H, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(B, N, H * D)
+    assert rel_l2(o, ref) < 6e-3

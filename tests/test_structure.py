@@ -181,3 +181,43 @@ def test_get_model_errors(tmp_path):
     (tmp_path / "config.yaml").write_text("unet_input_channels: 4\n")
     with pytest.raises(ValueError, match="No safetensors or ckpt"):
         get_model(str(tmp_path))
+
+
+def test_unet2d_refine_parameter_count_from_first_principles():
+    """UNet2DModel [64,128,256,256], in 6 / out 3 (src/lbm/inference/relight.py:356-366): the module tree's
+    parameter count against a count written out from the architecture (diffusers 0.32.2 UNet2DModel)."""
+    from lbm_amd.models.unets import DiffusersUNet2DWrapper
+
+    def conv(i, o, k=3):
+        return i * o * k * k + o
+
+    def lin(i, o):
+        return i * o + o
+
+    def resnet(i, o, t=256):
+        return 2 * i + conv(i, o) + lin(t, o) + 2 * o + conv(o, o) + (conv(i, o, 1) if i != o else 0)
+
+    ch = [64, 128, 256, 256]
+    total = conv(6, 64) + lin(64, 256) + lin(256, 256)
+    prev = 64
+    for i, c in enumerate(ch):
+        total += resnet(prev, c) + resnet(c, c) + (conv(c, c) if i < 3 else 0)
+        prev = c
+    total += 2 * resnet(256, 256) + 2 * 256 + 4 * lin(256, 256)                 # mid block: 2 resnets + attention
+    rch = ch[::-1]
+    prev = rch[0]
+    for i, c in enumerate(rch):
+        skip_in = rch[min(i + 1, 3)]
+        total += resnet(prev + c, c) + resnet(c + c, c) + resnet(c + skip_in, c) + (conv(c, c) if i < 3 else 0)
+        prev = c
+    total += 2 * 64 + conv(64, 3)
+    with torch.device("meta"):
+        m = DiffusersUNet2DWrapper(in_channels=6, out_channels=3, down_block_types=["DownBlock2D"] * 4,
+                                   up_block_types=["UpBlock2D"] * 4, block_out_channels=ch, layers_per_block=2, norm_num_groups=32)
+    assert _count(m) == total == 23_988_291
+    keys = set(m.state_dict().keys())
+    for k in ["conv_in.weight", "time_embedding.linear_2.bias", "down_blocks.3.resnets.1.conv2.weight", "down_blocks.2.downsamplers.0.conv.bias",
+              "mid_block.attentions.0.group_norm.weight", "mid_block.attentions.0.to_out.0.bias", "up_blocks.0.resnets.2.conv_shortcut.weight",
+              "up_blocks.2.upsamplers.0.conv.weight", "conv_norm_out.bias", "conv_out.weight"]:
+        assert k in keys, k
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in keys and "up_blocks.3.upsamplers.0.conv.weight" not in keys
