@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ partial,
                                                            int HW, int C, int G, int rows_per_slab, int nslab) {
-  extern __shared__ float sm[];   // [C8 chunk in block][16]: s1[8], s2[8]
+  extern __shared__ float sm[];   // [thread][16]: s1[8], s2[8]; reduced over the row lanes in a fixed order
   const int t = threadIdx.x;
   const int nch = C >> 3;                 // 8-channel chunks per row
   const int cpb = nch < 256 ? nch : 256;  // chunks handled per block pass (grid.y covers the rest)
@@ -281,11 +281,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
   const int chunk = blockIdx.y * cpb + t % cpb, rl = t / cpb;
   const int slab = blockIdx.x, b = blockIdx.z;
   const int cpg = C / G;
-  for (int i = t; i < cpb * 16; i += 256) sm[i] = 0.f;
-  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   if (chunk < nch && rl < rpp) {
     const int c0 = chunk * 8;
-    float a[8], sh[8], mu[8], rs[8], s1[8], s2[8];
+    float a[8], sh[8], mu[8], rs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int g = (c0 + e) / cpg;
@@ -293,7 +294,6 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
       rs[e] = stats[((int64_t)b * G + g) * 2 + 1];
       a[e] = gamma ? gamma[c0 + e] : 1.f;
       sh[e] = beta ? beta[c0 + e] : 0.f;
-      s1[e] = 0.f; s2[e] = 0.f;
     }
     const int r0 = slab * rows_per_slab, r1 = min(r0 + rows_per_slab, HW);
     const int64_t base = ((int64_t)b * HW) * C + c0;
@@ -309,19 +309,23 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
         s2[e] += dz * xh;
       }
     }
-    float* dst = sm + (t % cpb) * 16;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { atomicAdd(dst + e, s1[e]); atomicAdd(dst + 8 + e, s2[e]); }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sm[t * 16 + e] = s1[e]; sm[t * 16 + 8 + e] = s2[e]; }
   __syncthreads();
-  // partial[((b*nslab + slab)*C + c)*2 + {0,1}]
+  // partial[((b*nslab + slab)*C + c)*2 + {0,1}]: row lanes summed in order (no atomics: bit-reproducible)
   for (int i = t; i < cpb * 8; i += 256) {
     const int ck = i >> 3, e = i & 7;
     const int c = (blockIdx.y * cpb + ck) * 8 + e;
     if (c < C) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int r = 0; r < rpp; ++r) {
+        a1 += sm[(r * cpb + ck) * 16 + e];
+        a2 += sm[(r * cpb + ck) * 16 + 8 + e];
+      }
       float* p = partial + (((int64_t)b * nslab + slab) * C + c) * 2;
-      p[0] = sm[ck * 16 + e];
-      p[1] = sm[ck * 16 + 8 + e];
+      p[0] = a1;
+      p[1] = a2;
     }
   }
 }
@@ -400,11 +404,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ dx, const float* __restrict__ gamma,
                                                      float* __restrict__ partial, int rows, int C, float eps,
                                                      int rows_per_block) {
-  extern __shared__ float sm[];     // [2][C] block partials of dgamma, dbeta
+  extern __shared__ float sm[];     // [4 waves][2][C] partials of dgamma, dbeta, summed over the waves in order
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nchunks = C >> 3;
-  for (int i = t; i < 2 * C; i += 256) sm[i] = 0.f;
-  __syncthreads();
   float dg[NC][8], db[NC][8], ga[NC][8];
 #pragma unroll
   for (int i = 0; i < NC; ++i)
@@ -472,11 +474,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const int c = lane + 64 * i;
     if (c < nchunks) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { atomicAdd(&sm[c * 8 + e], dg[i][e]); atomicAdd(&sm[C + c * 8 + e], db[i][e]); }
+      for (int e = 0; e < 8; ++e) {
+        sm[wave * 2 * C + c * 8 + e] = dg[i][e];
+        sm[wave * 2 * C + C + c * 8 + e] = db[i][e];
+      }
     }
   }
   __syncthreads();
-  for (int i = t; i < 2 * C; i += 256) partial[(int64_t)blockIdx.x * 2 * C + i] = sm[i];
+  for (int i = t; i < 2 * C; i += 256)
+    partial[(int64_t)blockIdx.x * 2 * C + i] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------
@@ -595,7 +601,7 @@ extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
   float* gsum = bc + (int64_t)B * C * 2;
   const int nch = C / 8, cpb = nch < 256 ? nch : 256;
   dim3 grid(nslab, (nch + cpb - 1) / cpb, B);
-  const size_t shm = (size_t)cpb * 16 * sizeof(float);
+  const size_t shm = (size_t)256 * 16 * sizeof(float);
   if (silu)
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, grid, dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
                        beta, partial, HW, C, G, rows_per_slab, nslab);
@@ -634,7 +640,7 @@ extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const
   const int nblk = (int)(nfl / (2 * C));
   const int rpb = (rows + nblk - 1) / nblk;
   const int nc = (C / 8 + 63) / 64;
-  const size_t shm = (size_t)2 * C * sizeof(float);
+  const size_t shm = (size_t)4 * 2 * C * sizeof(float);
 #define LN_BWD(NC) hipLaunchKernelGGL(ln_bwd_kernel<NC>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, \
                                       (bf16_t*)dx, gamma, scratch, rows, C, eps, rpb)
   switch (nc) {

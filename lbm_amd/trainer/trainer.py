@@ -227,6 +227,50 @@ class TrainingPipeline(nn.Module):
             self.model.on_train_batch_end(train_batch)
         return {"loss": out["loss"].detach(), "batch_idx": out["batch_idx"]}
 
+    # ---- checkpoints (what Lightning's ModelCheckpoint / resume do in examples/training/train_base.py:27-53) ----
+    def save_checkpoint(self, path: str):
+        """Lightning-layout ``.ckpt``: ``state_dict`` keys carry the ``model.`` prefix (so ``get_model`` loads the
+        file), plus the optimizer moments and the step counter.  Tensors only: loadable with weights_only=True."""
+        ckpt = {"state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                "global_step": self.global_step}
+        if self.optims:
+            opt = self.optims[0]
+            sd = opt.state_dict()
+            if isinstance(opt, HipAdamW):
+                ckpt["optimizer_states"] = [{"step": sd["step"], "m": [t.cpu() for t in sd["m"]], "v": [t.cpu() for t in sd["v"]],
+                                             "numel": [g.numel for g in opt.groups]}]
+            else:
+                ckpt["optimizer_states"] = [sd]
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path: str, strict: bool = True):
+        """Restores parameters in place (they stay views of the flat buffers), optimizer state and the step."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in ckpt["state_dict"].items()}
+        own = self.model.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"checkpoint mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for k, t in own.items():
+                if k in sd:
+                    t.copy_(sd[k].to(t.dtype))
+        for p in self.model.parameters():
+            torch.autograd.graph.increment_version(p)
+        self.global_step = int(ckpt.get("global_step", 0))
+        states = ckpt.get("optimizer_states")
+        if states:
+            if not self.optims:
+                self.configure_optimizers()
+            opt = self.optims[0]
+            if isinstance(opt, HipAdamW):
+                st = states[0]
+                assert st["numel"] == [g.numel for g in opt.groups], "optimizer groups differ from the checkpoint's"
+                opt.load_state_dict({"step": st["step"], "m": st["m"], "v": st["v"]})
+            else:
+                opt.load_state_dict(states[0])
+
     def validation_step(self, val_batch: Dict[str, Any], val_idx: int) -> dict:
         with torch.no_grad():
             loss = self.model(val_batch)["loss"]

@@ -395,3 +395,39 @@ def test_lbm_forward_with_pixel_loss(cuda):
     grads = [p.grad for p in model.denoiser.parameters()]
     assert all(gd is not None and torch.isfinite(gd.float()).all() for gd in grads)
     assert all(p.grad is None for p in model.vae.parameters())
+
+
+def test_training_checkpoint_resume(cuda, tmp_path):
+    """save after 2 steps, keep training 2 more; a fresh pipeline restored from the file and trained on the same
+    2 batches ends bit-identical (parameters, moments, step), and get_model-style loading sees the weights."""
+    from lbm_amd.trainer import TrainingConfig, TrainingPipeline
+    cfg = TrainingConfig(learning_rate=1e-3, optimizer_name="AdamW", trainable_params=["denoiser.*"])
+    g = torch.Generator().manual_seed(3)
+    z, zs, eps = (torch.randn(2, 4, 32, 32, generator=g).to(BF).to(cuda) for _ in range(3))
+    ts = torch.tensor([500, 750], device=cuda)
+
+    def make():
+        model = _toy_lbm(cuda)
+        orig = model.forward
+        model.forward = lambda batch, *a, **k: orig(batch, bridge_eps=eps, timesteps=ts)
+        pipe = TrainingPipeline(model, cfg)
+        pipe.configure_optimizers()
+        return model, pipe
+
+    model, pipe = make()
+    for _ in range(2):
+        pipe.fit_step({"target": z, "source": zs})
+    path = str(tmp_path / "last.ckpt")
+    pipe.save_checkpoint(path)
+    for _ in range(2):
+        pipe.fit_step({"target": z, "source": zs})
+    model2, pipe2 = make()
+    pipe2.load_checkpoint(path)
+    assert pipe2.global_step == 2 and pipe2.optims[0].step_count == 2
+    for _ in range(2):
+        pipe2.fit_step({"target": z, "source": zs})
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    assert torch.equal(pipe.optims[0].groups[0].m, pipe2.optims[0].groups[0].m)
+    sd = torch.load(path, map_location="cpu", weights_only=True)["state_dict"]
+    assert all(k.startswith("model.") for k in sd) and "model.denoiser.conv_in.weight" in sd
