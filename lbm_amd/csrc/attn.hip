@@ -376,6 +376,49 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// Same softmax with the row held in registers (cols <= 1024 * NV): one read of the f32 scores instead of three.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                               int cols, int64_t ld_in, int64_t ld_out) {
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* s = S + (int64_t)blockIdx.x * ld_in;
+  bf16_t* p = P + (int64_t)blockIdx.x * ld_out;
+  const int nv = cols >> 2;
+  f32x4 v[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = t + 256 * k;
+    v[k] = i < nv ? *(const f32x4*)(s + 4 * i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[k][e] = __expf(v[k][e] - mx); sum += v[k][e]; }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = t + 256 * k;
+    if (i < nv) {
+      u16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.v[e] = f2bf(v[k][e] * inv);
+      *(u16x4*)(p + 4 * i) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o, int B,
@@ -416,7 +459,14 @@ extern "C" int lbmk_softmax_rows(const float* s, void* p, int64_t rows, int cols
   LBMK_REQUIRE(rows > 0 && rows < (1LL << 31) && cols > 0 && cols % 4 == 0, "softmax_rows: rows/cols");
   LBMK_REQUIRE(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= cols && ld_out >= cols, "softmax_rows: leading dims");
   LBMK_REQUIRE(lbmk_aligned(s, 16) && lbmk_aligned(p, 8), "softmax_rows: misaligned");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
-                     (bf16_t*)p, cols, ld_in, ld_out);
+#define SM_REG(NV) hipLaunchKernelGGL(softmax_rows_reg_kernel<NV>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, \
+                                      (bf16_t*)p, cols, ld_in, ld_out)
+  if (cols <= 1024) SM_REG(1);
+  else if (cols <= 4096) SM_REG(4);
+  else if (cols <= 16384) SM_REG(16);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
+                       (bf16_t*)p, cols, ld_in, ld_out);
+#undef SM_REG
   return lbmk_check_launch("softmax_rows");
 }
