@@ -1,5 +1,6 @@
-// Flash-style attention forward for head_dim 64 on v_mfma_f32_32x32x16_bf16 (gfx950),
-// plus the row softmax used by the unfused (head_dim 512) VAE attention.
+// Flash-style attention forward on v_mfma_f32_32x32x16_bf16 (gfx950): a tuned head_dim-64 kernel and a
+// generic one for head dims 8 ... 160 (multiples of 8, zero-padded to the MFMA shapes), plus the row
+// softmax used by the unfused (head_dim 512) VAE attention.
 //
 // One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.
 // Per 64-key tile:  S^T = K Q^T  (keys on the accumulator rows, the query row on the lane),
