@@ -112,12 +112,28 @@ int lbmk_layernorm(const void* x, void* y, const float* gamma, const float* beta
  *   vt : bf16 [B][H*D][ldvt]  (V transposed: row = channel, column = key)
  *   o  : bf16 [B][Nq][ldo]
  * Supported D: 8, 16, 32, 40, 64, 80, 160; keys at or past Nk are masked, ldvt >= Nk rounded up to 8.
+ *   lse : optional f32 [B][H][Nq], receives log2(sum_j exp(scale * q_i.k_j)) per row (what the
+ *         backward pass recomputes the probabilities from); NULL to skip.
  * ---------------------------------------------------------------------- */
 int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         int B, int H, int Nq, int Nk, int D,
                         int ldq, int ldk, int ldvt, int ldo,
                         int64_t sq, int64_t sk, int64_t svt, int64_t so,
-                        float scale, void* stream);
+                        float scale, float* lse, void* stream);
+
+/* Attention backward without materialised scores (torch autograd through
+ * F.scaled_dot_product_attention in the reference's training step,
+ * src/lbm/trainer/trainer.py:99-118 -> unet forward).  D = 64 only; Nq and Nk multiples of 128.
+ *   q, o, dout, dq : bf16 [B][Nq][ld]      k, v, dk, dv : bf16 [B][Nk][ld]     (head h at columns h*D ..)
+ *   qt, dout_t     : bf16 [B][H*D][ld_t_q] channel-major copies of q and dout;  kt : [B][H*D][ld_t_k]
+ *   lse            : f32 [B][H][Nq] from lbmk_flash_attn_fwd
+ *   delta          : f32 [B][H][Nq] scratch, receives rowsum(dout * o)
+ * sq / sk are the batch strides (elements) of the [.., Nq, ld] / [.., Nk, ld] tensors. */
+int lbmk_flash_attn_bwd(const void* q, const void* qt, const void* k, const void* kt,
+                        const void* v, const void* o, const void* dout, const void* dout_t,
+                        const float* lse, float* delta, void* dq, void* dk, void* dv,
+                        int B, int H, int Nq, int Nk, int D, int ld, int ld_t_q, int ld_t_k,
+                        int64_t sq, int64_t sk, float scale, void* stream);
 
 /* Row softmax: f32 scores [rows][ld_in] -> bf16 probabilities [rows][ld_out]
  * (unfused attention for the VAE mid-block: 1 head, head_dim 512). */

@@ -166,14 +166,24 @@ def _heads(t: torch.Tensor, H: int, D: int) -> torch.Tensor:
 
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale) v per head, heads interleaved along the channel axis ([B, N, H*D]).
-    Forward: the flash kernel.  Backward: probabilities are recomputed (q, k, v are all that is saved) and
-    every product is one implicit-GEMM launch batched over (image, head) through strided head views:
+    Forward: the flash kernel.  Backward, head_dim 64 with token counts that are multiples of 128: the fused
+    flash backward kernels (scores never materialised).  Otherwise probabilities are recomputed (q, k, v are
+    all that is saved) and every product is one implicit-GEMM launch batched over (image, head):
       dV = P^T dO,  dP = dO V^T,  dS = scale * P * (dP - rowsum(dP * P)),  dQ = dS K,  dK = dS^T Q."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads, dim_head, scale):
         if k.shape[1] % 8 or q.shape[1] % 8:
             raise NotImplementedError("training attention needs token counts that are multiples of 8")
+        ctx.cfg = (heads, dim_head, scale)
+        if (ops.flash_attn_bwd_supported(dim_head, q.shape[1], k.shape[1]) and q.is_contiguous()
+                and k.is_contiguous() and v.is_contiguous()):
+            # fused backward available: keep the output and the row log-sum-exp instead of recomputing P
+            o, lse = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale, return_lse=True)
+            ctx.save_for_backward(q, k, v, o, lse)
+            ctx.fused = True
+            return o
+        ctx.fused = False
         if dim_head in (40, 64, 80, 160):
             o = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale)
         else:
@@ -184,14 +194,16 @@ class AttentionFn(torch.autograd.Function):
             o = torch.empty_like(q)
             ops.gemm_nt(p, ops.transpose(v).view(B, heads, dim_head, k.shape[1]), out=_heads(o, heads, dim_head))
         ctx.save_for_backward(q, k, v)
-        ctx.cfg = (heads, dim_head, scale)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v = ctx.saved_tensors
         H, D, scale = ctx.cfg
         do = do.contiguous()
+        if ctx.fused:
+            q, k, v, o, lse = ctx.saved_tensors
+            return (*ops.flash_attn_bwd(q, k, v, o, do, lse, H, D, scale), None, None, None)
+        q, k, v = ctx.saved_tensors
         B, Nq, C = q.shape
         Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)

@@ -27,7 +27,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
-    int64_t sk, int64_t svt, int64_t so, float scale_log2e) {
+    int64_t sk, int64_t svt, int64_t so, float scale_log2e, float* __restrict__ LSE) {
   __shared__ __attribute__((aligned(16))) char smem[2 * KB * 128];
   char* sK = smem;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
   char* sV = smem + KB * 128;    // [d][64 keys]   same image
@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (q < Nq) {
+    // log2-domain log-sum-exp of the scaled scores, kept for the backward pass
+    if (LSE && h == 0) LSE[((int64_t)b * gridDim.y + head) * Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
     bf16_t* op = O + (int64_t)q * ldo;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -189,7 +191,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
-    int64_t sk, int64_t svt, int64_t so, float scale_log2e) {
+    int64_t sk, int64_t svt, int64_t so, float scale_log2e, float* __restrict__ LSE) {
   constexpr int KS = (DH + 15) / 16;     // 16-deep MFMA steps over the head dim
   constexpr int DT = (DH + 31) / 32;     // 32-row tiles of O^T
   constexpr int KROW = KS * 32;          // bytes per key row of the K image
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
   const float inv = 1.0f / l_tot;
   const int q = q0 + r;
   if (q < Nq) {
+    // log2-domain log-sum-exp of the scaled scores, kept for the backward pass
+    if (LSE && h == 0) LSE[((int64_t)b * gridDim.y + head) * Nq + q] = m_run + __builtin_amdgcn_logf(l_tot);
     bf16_t* op = O + (int64_t)q * ldo;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
 extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o, int B,
                                    int H, int Nq, int Nk, int Dh, int ldq, int ldk, int ldvt,
                                    int ldo, int64_t sq, int64_t sk, int64_t svt, int64_t so,
-                                   float scale, void* stream) {
+                                   float scale, float* lse, void* stream) {
   LBMK_REQUIRE(q && k && vt && o, "flash_attn: null pointer");
   LBMK_REQUIRE(Dh == 64 || Dh == 40 || Dh == 80 || Dh == 160 || Dh == 8 || Dh == 16 || Dh == 32,
                "flash_attn: head_dim %d not supported (8, 16, 32, 40, 64, 80, 160)", Dh);
@@ -440,7 +444,7 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
   dim3 grid((Nq + QB - 1) / QB, H, B);
   hipStream_t s = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
-#define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2
+#define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2, lse
   switch (Dh) {
     case 64: hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, s, FA_ARGS); break;
     case 8: hipLaunchKernelGGL(flash_fwd_gen_kernel<8>, grid, dim3(256), 0, s, FA_ARGS); break;

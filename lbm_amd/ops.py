@@ -367,8 +367,9 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
 # attention
 # --------------------------------------------------------------------------------------
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, head_dim: int,
-               scale: Optional[float] = None) -> torch.Tensor:
-    """q: [B, Nq, >=H*D] (last-dim view allowed), k: [B, Nk, >=H*D], vt: [B, H*D, Nk]."""
+               scale: Optional[float] = None, return_lse: bool = False):
+    """q: [B, Nq, >=H*D] (last-dim view allowed), k: [B, Nk, >=H*D], vt: [B, H*D, Nk].
+    ``return_lse``: also return the f32 [B, H, Nq] log2-sum-exp rows ``flash_attn_bwd`` consumes."""
     _need_gpu(q, k, vt)
     assert q.dtype == bf16 and k.dtype == bf16 and vt.dtype == bf16
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and vt.stride(-1) == 1
@@ -377,11 +378,40 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, h
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
     o = torch.empty(B, Nq, heads * head_dim, dtype=bf16, device=q.device)
+    lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device) if return_lse else None
     check(lib.lbmk_flash_attn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, heads, Nq, Nk,
                                   head_dim, q.stride(1), k.stride(1), vt.stride(1), o.stride(1),
-                                  q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale, _stream()),
+                                  q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale,
+                                  lse.data_ptr() if return_lse else None, _stream()),
           "lbmk_flash_attn_fwd")
-    return o
+    return (o, lse) if return_lse else o
+
+
+FLASH_BWD_HEAD_DIMS = (64,)
+
+
+def flash_attn_bwd_supported(head_dim: int, Nq: int, Nk: int) -> bool:
+    return head_dim in FLASH_BWD_HEAD_DIMS and Nq % 128 == 0 and Nk % 128 == 0
+
+
+def flash_attn_bwd(q, k, v, o, do, lse, heads: int, head_dim: int, scale: float):
+    """Gradients of softmax(q k^T * scale) v for contiguous bf16 [B, N, H*D] tensors, scores never
+    materialised.  Returns (dq, dk, dv)."""
+    _need_gpu(q, k, v, o, do, lse)
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    assert C == heads * head_dim and flash_attn_bwd_supported(head_dim, Nq, Nk)
+    for t in (q, k, v, o, do):
+        assert t.dtype == bf16 and t.is_contiguous() and t.shape[2] == C
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (B, heads, Nq)
+    qt, kt, dot = transpose(q), transpose(k), transpose(do)          # [B, C, N]
+    delta = torch.empty_like(lse)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(lib.lbmk_flash_attn_bwd(q.data_ptr(), qt.data_ptr(), k.data_ptr(), kt.data_ptr(), v.data_ptr(),
+                                  o.data_ptr(), do.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, head_dim, C,
+                                  Nq, Nk, Nq * C, Nk * C, scale, _stream()), "lbmk_flash_attn_bwd")
+    return dq, dk, dv
 
 
 def softmax_rows(s: torch.Tensor) -> torch.Tensor:

@@ -51,8 +51,9 @@ def test_relight_builders_structure():
     keys = set(f.state_dict().keys())
     assert "conditioner.conditioners.1.group_fourier.0.B" in keys
     assert "conditioner.conditioners.1.group_mlps.4.4.bias" in keys
-    with pytest.raises(NotImplementedError):
-        build_filllight_refine_model()
+    with torch.device("meta"):
+        rf = build_filllight_refine_model()
+    assert sum(p.numel() for p in rf.denoiser.parameters()) == 23_988_291
 
 
 def test_lighting_embedder_shapes_and_rng_alignment():
