@@ -123,7 +123,7 @@ int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 
 /* Attention backward without materialised scores (torch autograd through
  * F.scaled_dot_product_attention in the reference's training step,
- * src/lbm/trainer/trainer.py:99-118 -> unet forward).  D = 64 only; Nq and Nk multiples of 128.
+ * src/lbm/trainer/trainer.py:99-118 -> unet forward).  D = 40, 64, 80 or 160; Nq and Nk multiples of 64.
  *   q, o, dout, dq : bf16 [B][Nq][ld]      k, v, dk, dv : bf16 [B][Nk][ld]     (head h at columns h*D ..)
  *   qt, dout_t     : bf16 [B][H*D][ld_t_q] channel-major copies of q and dout;  kt : [B][H*D][ld_t_k]
  *   lse            : f32 [B][H][Nq] from lbmk_flash_attn_fwd

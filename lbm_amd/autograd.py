@@ -166,7 +166,7 @@ def _heads(t: torch.Tensor, H: int, D: int) -> torch.Tensor:
 
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale) v per head, heads interleaved along the channel axis ([B, N, H*D]).
-    Forward: the flash kernel.  Backward, head_dim 64 with token counts that are multiples of 128: the fused
+    Forward: the flash kernel.  Backward, head dims 40 / 64 / 80 / 160 with token counts that are multiples of 64: the fused
     flash backward kernels (scores never materialised).  Otherwise probabilities are recomputed (q, k, v are
     all that is saved) and every product is one implicit-GEMM launch batched over (image, head):
       dV = P^T dO,  dP = dO V^T,  dS = scale * P * (dP - rowsum(dP * P)),  dQ = dS K,  dK = dS^T Q."""

@@ -162,15 +162,33 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   }
 }
 
-// out[g][n] (+)= sum over segments; out dtype 0 bf16 / 1 f32
-__global__ void colsum_final_kernel(const float* __restrict__ partial, void* __restrict__ out, int64_t GN, int nseg,
-                                    int out_dtype) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= GN) return;
-  float a = 0.f;
-  for (int s = 0; s < nseg; ++s) a += partial[(int64_t)s * GN + i];
-  if (out_dtype) ((float*)out)[i] = a;
-  else ((bf16_t*)out)[i] = f2bf(a);
+// out[i] = sum over segments of partial[s][i]; out dtype 0 bf16 / 1 f32.  32 columns per workgroup, 8 segment
+// lanes per column with independent loads in flight; the 8 lane sums are added in a fixed order.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, void* __restrict__ out,
+                                                           int64_t GN, int nseg, int out_dtype) {
+  __shared__ float red[8][33];
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < GN) {
+    int s = sl;
+    for (; s + 24 < nseg; s += 32) {
+      a0 += partial[(int64_t)s * GN + i];
+      a1 += partial[(int64_t)(s + 8) * GN + i];
+      a2 += partial[(int64_t)(s + 16) * GN + i];
+      a3 += partial[(int64_t)(s + 24) * GN + i];
+    }
+    for (; s < nseg; s += 8) a0 += partial[(int64_t)s * GN + i];
+  }
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (t < 32 && i < GN) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k][t];
+    if (out_dtype) ((float*)out)[i] = a;
+    else ((bf16_t*)out)[i] = f2bf(a);
+  }
 }
 
 }  // namespace
@@ -247,7 +265,7 @@ extern "C" int lbmk_colsum(const void* x, void* out, float* scratch, int64_t row
   hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scratch,
                      rows_per_group, N, ld, nseg);
   const int64_t GN = groups * N;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((GN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((GN + 31) / 32)), dim3(256), 0, (hipStream_t)stream, scratch,
                      out, GN, nseg, out_dtype);
   return lbmk_check_launch("colsum");
 }
@@ -652,7 +670,7 @@ extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const
 #undef LN_BWD
   // block partials are [nblk][2][C]: row 0 dgamma, row 1 dbeta
   if (dgamma_dbeta)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, scratch, (void*)dgamma_dbeta,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, scratch, (void*)dgamma_dbeta,
                        (int64_t)2 * C, nblk, 1);
   return lbmk_check_launch("layernorm_bwd");
 }

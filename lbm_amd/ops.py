@@ -387,11 +387,11 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, h
     return (o, lse) if return_lse else o
 
 
-FLASH_BWD_HEAD_DIMS = (64,)
+FLASH_BWD_HEAD_DIMS = (40, 64, 80, 160)
 
 
 def flash_attn_bwd_supported(head_dim: int, Nq: int, Nk: int) -> bool:
-    return head_dim in FLASH_BWD_HEAD_DIMS and Nq % 128 == 0 and Nk % 128 == 0
+    return head_dim in FLASH_BWD_HEAD_DIMS and Nq % 64 == 0 and Nk % 64 == 0
 
 
 def flash_attn_bwd(q, k, v, o, do, lse, heads: int, head_dim: int, scale: float):

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--ops", action="store_true", help="after timing, count aten ops of one step by calling line")
     args = ap.parse_args()
     rank, local_rank, world = D.env_world()
     device = torch.device("cuda", local_rank)
@@ -53,6 +54,21 @@ def main():
                           "ms_per_step": round(el / args.steps * 1e3, 1), "dtype": "bf16", "data": "synthetic",
                           "achieved_tflops": round(sps * 7.31, 1), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
                           "loss": float(loss)}))
+
+
+    if args.ops and rank == 0:
+        from collections import Counter
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+            pipe.fit_step(batch)
+            torch.cuda.synchronize()
+        cnt = Counter()
+        for ev in prof.events():
+            if ev.name in ("aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::contiguous", "aten::cat", "aten::fill_", "aten::mul"):
+                frames = [f for f in (ev.stack or []) if "lbm_amd" in f]
+                cnt[(ev.name, frames[0].split("lbm_amd/")[-1] if frames else "autograd engine")] += 1
+        for (name, where), n in cnt.most_common(40):
+            print(f"{n:6d} {name:18s} {where}")
 
 
 if __name__ == "__main__":
