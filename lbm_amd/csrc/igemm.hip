@@ -447,7 +447,10 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {512, 128},    // 8: 16 waves, for N = 128 layers
                           {256, 128},    // 9: 16 waves (64x32 per wave)
                           {256, 128},    // 10: 8 waves, single-buffered, two workgroups per CU
-                          {256, 160}};   // 11: 16 waves (32x80 per wave): the UNet widths 320 ... 2560 are multiples of 160
+                          {256, 160},    // 11: 16 waves (32x80 per wave): the UNet widths 320 ... 2560 are multiples of 160
+                          {128, 64},     // 12: tile 1 double-buffered (small grids: few workgroups per CU to overlap with)
+                          {64, 64},      // 13: tile 3 double-buffered
+                          {128, 128}};   // 14: tile 0 double-buffered
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
@@ -531,27 +534,32 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
     else {
-      // Cost model over the production tiles.  A tile shape keeps `resident` workgroups on a CU and
-      // then sustains `rate` (measured, TFLOP/s at full occupancy, mid-size K); padded rows / columns
-      // are paid in full.  One-per-CU tiles run in whole rounds of the CU count; co-resident tiles
-      // drain more smoothly (a CU with fewer workgroups left runs them faster): their round count is
-      // whole workgroups per CU divided by the residency, floored at half a round.
-      struct Cand { int tile, bm, bn, resident; float rate; };
-      static const Cand cands[] = {{7, 256, 256, 1, 1300.f}, {11, 256, 160, 1, 1200.f}, {8, 512, 128, 1, 1150.f},
-                                   {10, 256, 128, 2, 1170.f}, {0, 128, 128, 4, 1130.f}, {1, 128, 64, 4, 920.f},
-                                   {3, 64, 64, 8, 750.f}};
+      // Cost model over the production tiles: time of the busiest CU.  A CU holding w workgroups of a
+      // tile runs them `resident` at a time; a round of n co-resident workgroups costs a fixed part
+      // (prologue + epilogue) plus, per 64-deep K step, max(n * tc, L [+ tc when single-buffered]):
+      // tc = MFMA/LDS time of one workgroup's step, L = exposed load + barrier latency, which only
+      // co-resident workgroups (or the second stage buffer) can hide.  Constants (microseconds) are
+      // least-squares fits to measured GEMMs, M 1k..16k, N 320..10k, K 640..5k; padded rows / columns
+      // are paid in full.
+      struct Cand { int tile, bm, bn, resident; bool dbuf; float a, o, tc, L; };
+      static const Cand cands[] = {{7, 256, 256, 1, true, 0.f, 13.7f, 1.01f, 1.20f},  {11, 256, 160, 1, true, 0.f, 10.1f, 1.02f, 1.05f},
+                                   {8, 512, 128, 1, true, 0.f, 13.7f, 1.14f, 1.20f},  {10, 256, 128, 2, false, 0.f, 8.3f, 0.87f, 0.38f},
+                                   {0, 128, 128, 4, false, 2.8f, 4.8f, 0.55f, 0.34f}, {1, 128, 64, 4, false, 5.0f, 1.9f, 0.34f, 0.23f},
+                                   {3, 64, 64, 8, false, 2.5f, 2.2f, 0.25f, 0.30f},   {12, 128, 64, 3, true, 1.9f, 4.5f, 0.34f, 0.55f},
+                                   {13, 64, 64, 4, true, 3.3f, 2.0f, 0.24f, 0.42f},   {14, 128, 128, 2, true, 0.f, 7.9f, 0.20f, 0.84f}};
       const int cus = lbmk_num_cus();
+      const int nkt = (d.K + 63) / 64;
       double best = 1e300;
       tile = 0;
       for (const Cand& c : cands) {
-        if (gn && (c.tile == 1 || c.tile == 3 || c.tile == 11)) continue;   // statistics strips are 64 rows x 64 columns per wave
+        if (gn && !(c.tile == 0 || c.tile == 7 || c.tile == 8 || c.tile == 10 || c.tile == 14)) continue;   // statistics strips are 64 rows x 64 columns per wave
         if (d.act == LBMK_ACT_GEGLU && c.tile == 11) continue;              // odd number of column groups per wave
         const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
-        const long per_cu = (blocks + cus - 1) / cus;
-        double rounds = (double)per_cu / c.resident;
-        if (c.resident == 1) rounds = (double)per_cu;
-        else if (rounds < 0.5) rounds = 0.5;
-        const double cost = rounds * c.resident * c.bm * c.bn / c.rate;
+        long w = (blocks + cus - 1) / cus;
+        const long full = w / c.resident;
+        const int rest = (int)(w - full * c.resident);
+        auto round_cost = [&](int n) { const double lat = c.dbuf ? c.L : c.L + c.tc; const double st = n * c.tc > lat ? n * c.tc : lat; return c.o + nkt * st; };
+        double cost = c.a + full * round_cost(c.resident) + (rest ? round_cost(rest) : 0.0);
         if (cost < best) { best = cost; tile = c.tile; }
       }
     }
@@ -560,7 +568,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
-  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10, "igemm: tile %d has no 64x64 wave strips", tile);
+  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14, "igemm: tile %d has no 64x64 wave strips", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
     case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;
@@ -575,6 +583,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 9: launch<256, 128, 4, 4, true>(d, s); break;
     case 10: launch<256, 128, 4, 2, false, false, 2>(d, s); break;
     case 11: launch<256, 160, 8, 2, true>(d, s); break;
+    case 12: launch<128, 64, 2, 2, true, false, 3>(d, s); break;
+    case 13: launch<64, 64, 2, 2, true, false, 4>(d, s); break;
+    case 14: launch<128, 128, 2, 2, true, false, 2>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
