@@ -124,16 +124,18 @@ int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 /* Attention backward without materialised scores (torch autograd through
  * F.scaled_dot_product_attention in the reference's training step,
  * src/lbm/trainer/trainer.py:99-118 -> unet forward).  D = 40, 64, 80 or 160; Nq and Nk multiples of 64.
- *   q, o, dout, dq : bf16 [B][Nq][ld]      k, v, dk, dv : bf16 [B][Nk][ld]     (head h at columns h*D ..)
- *   qt, dout_t     : bf16 [B][H*D][ld_t_q] channel-major copies of q and dout;  kt : [B][H*D][ld_t_k]
- *   lse            : f32 [B][H][Nq] from lbmk_flash_attn_fwd
- *   delta          : f32 [B][H][Nq] scratch, receives rowsum(dout * o)
- * sq / sk are the batch strides (elements) of the [.., Nq, ld] / [.., Nk, ld] tensors. */
+ *   q, dq : bf16 [B][Nq][ld]   k, v, dk, dv : bf16 [B][Nk][ld]   o, dout : bf16 [B][Nq][ld_o]   (head h at
+ *           columns h*D ..; q / k / v may be column windows of one packed projection output, ld its width)
+ *   qt, dout_t : bf16 [B][H*D][ld_t_q] channel-major copies of q and dout;  kt : [B][H*D][ld_t_k]
+ *   lse    : f32 [B][H][Nq] from lbmk_flash_attn_fwd
+ *   delta  : f32 [B][H][Nq] scratch, receives rowsum(dout * o)
+ * Batch strides (elements): sq (q, dq), sk (k, v, dk, dv), so (o, dout), sqt (qt), sdot (dout_t), skt (kt). */
 int lbmk_flash_attn_bwd(const void* q, const void* qt, const void* k, const void* kt,
                         const void* v, const void* o, const void* dout, const void* dout_t,
                         const float* lse, float* delta, void* dq, void* dk, void* dv,
-                        int B, int H, int Nq, int Nk, int D, int ld, int ld_t_q, int ld_t_k,
-                        int64_t sq, int64_t sk, float scale, void* stream);
+                        int B, int H, int Nq, int Nk, int D, int ld, int ld_o, int ld_t_q, int ld_t_k,
+                        int64_t sq, int64_t sk, int64_t so, int64_t sqt, int64_t sdot, int64_t skt,
+                        float scale, void* stream);
 
 /* Row softmax: f32 scores [rows][ld_in] -> bf16 probabilities [rows][ld_out]
  * (unfused attention for the VAE mid-block: 1 head, head_dim 512). */

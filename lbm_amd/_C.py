@@ -63,7 +63,7 @@ SIGNATURES = {
     "lbmk_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "lbmk_flash_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                   i64, i64, i64, i64, f32, vp, vp]),
-    "lbmk_flash_attn_bwd": (i32, [vp] * 13 + [i32] * 8 + [i64, i64, f32, vp]),
+    "lbmk_flash_attn_bwd": (i32, [vp] * 13 + [i32] * 9 + [i64] * 6 + [f32, vp]),
     "lbmk_softmax_rows": (i32, [vp, vp, i64, i32, i64, i64, vp]),
     "lbmk_bridge_interp": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, f32, i32, i32, vp]),
     "lbmk_euler_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, i32, vp]),

@@ -223,6 +223,48 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class SelfAttnQKVFn(torch.autograd.Function):
+    """Self-attention whose three bias-free input projections run as ONE GEMM over the stacked weights:
+    qkv = x @ [W_a; W_b; W_c]^T, o = softmax(q k^T * scale) v.  ``mod`` (the attention module) supplies the
+    stacked packed weight, its transpose and the column order of (q, k, v) in the stack.  Backward: the fused
+    flash kernels write dq / dk / dv into one [B, N, 3C] buffer, so the input gradient and the weight
+    gradient are one GEMM each as well (instead of three plus two accumulations)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, mod, heads, dim_head, scale):
+        C = heads * dim_head
+        pw, cols = mod.packed_qkv()
+        qkv = ops.linear(x, pw)                                                   # [B, N, 3C]
+        q, k, v = (qkv[..., cols[r]:cols[r] + C] for r in "qkv")
+        o, lse = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale, return_lse=True)
+        ctx.save_for_backward(x, qkv, o, lse)
+        ctx.mod, ctx.cfg, ctx.cols, ctx.wdt = mod, (heads, dim_head, scale), cols, wq.dtype
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, qkv, o, lse = ctx.saved_tensors
+        H, D, scale = ctx.cfg
+        C, cols = H * D, ctx.cols
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        qkvt = ops.transpose(qkv)                                                 # [B, 3C, N]
+        q, k, v = (qkv[..., cols[r]:cols[r] + C] for r in "qkv")
+        dq, dk, dv = (dqkv[..., cols[r]:cols[r] + C] for r in "qkv")
+        ops.flash_attn_bwd(q, k, v, o, do, lse, H, D, scale, out=(dq, dk, dv),
+                           transposed=(qkvt[:, cols["q"]:cols["q"] + C], qkvt[:, cols["k"]:cols["k"] + C]))
+        d2, x2 = _rows(dqkv), _rows(x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(d2, ctx.mod.packed_qkv_t())[:, :x.shape[-1]].reshape(x.shape)
+        dws = [None, None, None]
+        if any(ctx.needs_input_grad[1:4]):
+            dw = ops.gemm_tn(d2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=ctx.wdt)   # [3C, K]
+            dws = [dw[cols[r]:cols[r] + C, :x.shape[-1]] if ctx.needs_input_grad[1 + i] else None
+                   for i, r in enumerate("qkv")]
+        return (dx, *dws, None, None, None, None)
+
+
 class NchwToNhwcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dq_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
     const float* __restrict__ LSE, bf16_t* __restrict__ dQ, float* __restrict__ Delta, int Nq, int Nk,
-    int ld, int ldkt, int64_t sq, int64_t sk, int64_t skt, float scale, float scale_log2e) {
+    int ld, int ldo, int ldkt, int64_t sq, int64_t sk, int64_t so, int64_t skt, float scale, float scale_log2e) {
   constexpr int KS = (DH + 15) / 16, DT = (DH + 31) / 32, KROW = KS * 32;
   __shared__ __attribute__((aligned(16))) char smem[2 * TB * KROW + DT * 32 * 128];
   char* sK = smem;                  // [key][DH]
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dq_kernel(
   K += b * sk + head * DH;
   V += b * sk + head * DH;
   Kt += b * skt + (int64_t)head * DH * ldkt;
-  dO += b * sq + head * DH;
-  O += b * sq + head * DH;
+  dO += b * so + head * DH;
+  O += b * so + head * DH;
   dQ += b * sq + head * DH;
   const int64_t stat = ((int64_t)b * H + head) * Nq + qc;
 
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dq_kernel(
   {
     bf16x8 of[KS];
     load_row_frags<DH>(Q + (int64_t)qc * ld, h, qf);
-    load_row_frags<DH>(dO + (int64_t)qc * ld, h, dof);
-    load_row_frags<DH>(O + (int64_t)qc * ld, h, of);
+    load_row_frags<DH>(dO + (int64_t)qc * ldo, h, dof);
+    load_row_frags<DH>(O + (int64_t)qc * ldo, h, of);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dkv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ K,
     const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOt,
     const float* __restrict__ LSE, const float* __restrict__ Delta, bf16_t* __restrict__ dK,
-    bf16_t* __restrict__ dV, int Nq, int Nk, int ld, int ldqt, int64_t sq, int64_t sqt, int64_t sk,
-    float scale, float scale_log2e) {
+    bf16_t* __restrict__ dV, int Nq, int Nk, int ld, int ldo, int ldqt, int64_t sq, int64_t sqt, int64_t sk,
+    int64_t so, int64_t sdot, float scale, float scale_log2e) {
   constexpr int KS = (DH + 15) / 16, DT = (DH + 31) / 32, KROW = KS * 32;
   constexpr bool DO_DV = (WANT & 1) != 0, DO_DK = (WANT & 2) != 0;
   __shared__ __attribute__((aligned(16))) char smem[2 * TB * KROW + 2 * DT * 32 * 128 + 2 * TB * 4];
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dkv_kernel(
   Qt += b * sqt + (int64_t)head * DH * ldqt;
   K += b * sk + head * DH;
   V += b * sk + head * DH;
-  dO += b * sq + head * DH;
-  dOt += b * sqt + (int64_t)head * DH * ldqt;
+  dO += b * so + head * DH;
+  dOt += b * sdot + (int64_t)head * DH * ldqt;
   dK += b * sk + head * DH;
   dV += b * sk + head * DH;
   LSE += ((int64_t)b * H + head) * Nq;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dkv_kernel(
   for (int q0 = 0; q0 < Nq; q0 += TB) {
     stage_rows<DH>(Q + (int64_t)q0 * ld, ld, sQ, t, wave);
     if constexpr (DO_DK) {
-      stage_rows<DH>(dO + (int64_t)q0 * ld, ld, sG, t, wave);
+      stage_rows<DH>(dO + (int64_t)q0 * ldo, ldo, sG, t, wave);
       stage_cols<DH>(Qt + q0, ldqt, sQt, wave, rsub, cs);
     }
     if constexpr (DO_DV) stage_cols<DH>(dOt + q0, ldqt, sGt, wave, rsub, cs);
@@ -314,17 +314,16 @@ __global__ __launch_bounds__(256, DH > 80 ? 1 : 2) void flash_bwd_dkv_kernel(
 template <int DH>
 void launch_bwd(const void* q, const void* qt, const void* k, const void* kt, const void* v, const void* o,
                 const void* dout, const void* dout_t, const float* lse, float* delta, void* dq, void* dk, void* dv,
-                int B, int H, int Nq, int Nk, int ld, int ld_t_q, int ld_t_k, int64_t sq, int64_t sk, float scale,
-                hipStream_t s) {
+                int B, int H, int Nq, int Nk, int ld, int ld_o, int ld_t_q, int ld_t_k, int64_t sq, int64_t sk,
+                int64_t so, int64_t sqt, int64_t sdot, int64_t skt, float scale, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
-  const int64_t sqt = (int64_t)H * DH * ld_t_q, skt = (int64_t)H * DH * ld_t_k;   // channel-major copies: [B][H*DH][ld_t]
   hipLaunchKernelGGL(flash_bwd_dq_kernel<DH>, dim3((Nq + RB - 1) / RB, H, B), dim3(256), 0, s, (const bf16_t*)q,
                      (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)kt, (const bf16_t*)dout, (const bf16_t*)o, lse,
-                     (bf16_t*)dq, delta, Nq, Nk, ld, ld_t_k, sq, sk, skt, scale, sl2);
+                     (bf16_t*)dq, delta, Nq, Nk, ld, ld_o, ld_t_k, sq, sk, so, skt, scale, sl2);
 #define DKV(WANT)                                                                                                       \
   hipLaunchKernelGGL((flash_bwd_dkv_kernel<DH, WANT>), dim3((Nk + RB - 1) / RB, H, B), dim3(256), 0, s, (const bf16_t*)q, \
                      (const bf16_t*)qt, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, (const bf16_t*)dout_t,  \
-                     lse, delta, (bf16_t*)dk, (bf16_t*)dv, Nq, Nk, ld, ld_t_q, sq, sqt, sk, scale, sl2)
+                     lse, delta, (bf16_t*)dk, (bf16_t*)dv, Nq, Nk, ld, ld_o, ld_t_q, sq, sqt, sk, so, sdot, scale, sl2)
   if constexpr (DH == 80) { DKV(1); DKV(2); }   // measured: two lighter walks beat one at a single wave per SIMD
   else DKV(3);
 #undef DKV
@@ -335,24 +334,28 @@ void launch_bwd(const void* q, const void* qt, const void* k, const void* kt, co
 extern "C" int lbmk_flash_attn_bwd(const void* q, const void* qt, const void* k, const void* kt,
                                    const void* v, const void* o, const void* dout, const void* dout_t,
                                    const float* lse, float* delta, void* dq, void* dk, void* dv, int B,
-                                   int H, int Nq, int Nk, int Dh, int ld, int ld_t_q, int ld_t_k,
-                                   int64_t sq, int64_t sk, float scale, void* stream) {
+                                   int H, int Nq, int Nk, int Dh, int ld, int ld_o, int ld_t_q, int ld_t_k,
+                                   int64_t sq, int64_t sk, int64_t so, int64_t sqt, int64_t sdot, int64_t skt,
+                                   float scale, void* stream) {
   LBMK_REQUIRE(q && qt && k && kt && v && o && dout && dout_t && lse && delta && dq && dk && dv,
                "flash_attn_bwd: null pointer");
   LBMK_REQUIRE(Dh == 64 || Dh == 40 || Dh == 80 || Dh == 160, "flash_attn_bwd: head_dim %d not supported (40, 64, 80, 160)", Dh);
   LBMK_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "flash_attn_bwd: sizes");
   LBMK_REQUIRE(Nq > 0 && Nk > 0 && Nq % TB == 0 && Nk % TB == 0,
                "flash_attn_bwd: token counts (%d, %d) must be multiples of %d", Nq, Nk, TB);
-  LBMK_REQUIRE(ld % 8 == 0 && ld >= H * Dh && ld_t_q % 8 == 0 && ld_t_q >= Nq && ld_t_k % 8 == 0 && ld_t_k >= Nk,
-               "flash_attn_bwd: leading dims");
-  LBMK_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && sq >= (int64_t)Nq * ld && sk >= (int64_t)Nk * ld,
+  LBMK_REQUIRE(ld % 8 == 0 && ld >= H * Dh && ld_o % 8 == 0 && ld_o >= H * Dh && ld_t_q % 8 == 0 && ld_t_q >= Nq &&
+                   ld_t_k % 8 == 0 && ld_t_k >= Nk, "flash_attn_bwd: leading dims");
+  LBMK_REQUIRE(sq % 8 == 0 && sk % 8 == 0 && so % 8 == 0 && sqt % 8 == 0 && sdot % 8 == 0 && skt % 8 == 0 &&
+                   sq >= (int64_t)Nq * ld && sk >= (int64_t)Nk * ld && so >= (int64_t)Nq * ld_o &&
+                   sqt >= (int64_t)H * Dh * ld_t_q && sdot >= (int64_t)H * Dh * ld_t_q && skt >= (int64_t)H * Dh * ld_t_k,
                "flash_attn_bwd: batch strides");
   LBMK_REQUIRE(lbmk_aligned(q, 16) && lbmk_aligned(qt, 16) && lbmk_aligned(k, 16) && lbmk_aligned(kt, 16) &&
                    lbmk_aligned(v, 16) && lbmk_aligned(o, 16) && lbmk_aligned(dout, 16) &&
                    lbmk_aligned(dout_t, 16) && lbmk_aligned(dq, 8) && lbmk_aligned(dk, 8) && lbmk_aligned(dv, 8),
                "flash_attn_bwd: misaligned pointer");
   hipStream_t s = (hipStream_t)stream;
-#define BWD(DH) launch_bwd<DH>(q, qt, k, kt, v, o, dout, dout_t, lse, delta, dq, dk, dv, B, H, Nq, Nk, ld, ld_t_q, ld_t_k, sq, sk, scale, s)
+#define BWD(DH) launch_bwd<DH>(q, qt, k, kt, v, o, dout, dout_t, lse, delta, dq, dk, dv, B, H, Nq, Nk, ld, ld_o, ld_t_q, ld_t_k, \
+                               sq, sk, so, sqt, sdot, skt, scale, s)
   switch (Dh) {
     case 40: BWD(40); break;
     case 64: BWD(64); break;

@@ -78,6 +78,36 @@ class Attention(nn.Module, _Cached):
             return pw.w, b
         return self._cached("v", (self.to_v.weight, self.to_v.bias), build)
 
+    def _qkv_stack(self):
+        """(stacked [3C, K] weight, column offset of q / k / v in the stack).  When the three weights lie back
+        to back in one buffer (the trainer re-homes parameters into flat buffers) the stack is a view."""
+        ws = sorted((("q", self.to_q.weight), ("k", self.to_k.weight), ("v", self.to_v.weight)),
+                    key=lambda t: t[1].data_ptr())
+        C, K = self.inner_dim, self.to_q.weight.shape[1]
+        first = ws[0][1]
+        adjacent = all(w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape == first.shape and
+                       w.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for _, w in ws) and \
+            all(ws[i][1].data_ptr() + C * K * 2 == ws[i + 1][1].data_ptr() for i in range(2))
+        if adjacent:
+            stack = torch.as_strided(first.detach(), (3 * C, K), (K, 1))
+        else:
+            stack = torch.cat([w.detach() for _, w in ws], 0)
+        return stack, {r: i * C for i, (r, _) in enumerate(ws)}
+
+    def packed_qkv(self):
+        def build():
+            stack, cols = self._qkv_stack()
+            return ops.pack_linear_weight(stack, None), cols
+        return self._cached("qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight), build)
+
+    def packed_qkv_t(self):
+        def build():
+            stack, _ = self._qkv_stack()
+            if stack.dtype == torch.bfloat16 and stack.shape[1] % 8 == 0:
+                return ops.pack_linear_weight(ops.transpose(stack), None)
+            return ops.pack_linear_weight(stack.t().contiguous(), None)
+        return self._cached("qkvt", (self.to_q.weight, self.to_k.weight, self.to_v.weight), build)
+
     def forward(self, xn, ctx, residual):
         """xn: normalised tokens [B, N, C]; ctx None => self-attention over xn (the reference passes
         encoder_hidden_states=None with cross_attention_dim == C, so attn2 is a self-attention too);
@@ -87,7 +117,13 @@ class Attention(nn.Module, _Cached):
         C = self.inner_dim
         if training(xn, self.to_q.weight):
             # differentiable route: separate projections, attention with a hand-written backward
-            from ...autograd import AttentionFn
+            from ...autograd import AttentionFn, SelfAttnQKVFn
+            if (ctx is None and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None
+                    and self.to_q.weight.shape == self.to_k.weight.shape and xn.shape[-1] % 8 == 0
+                    and ops.flash_attn_bwd_supported(self.dim_head, xn.shape[1], xn.shape[1])):
+                o = SelfAttnQKVFn.apply(xn, self.to_q.weight, self.to_k.weight, self.to_v.weight, self,
+                                        self.heads, self.dim_head, self.dim_head ** -0.5)
+                return self.to_out[0](o, residual=residual)
             src = xn if ctx is None else ctx.to(torch.bfloat16).contiguous()
             q, k, v = self.to_q(xn), self.to_k(src), self.to_v(src)
             o = AttentionFn.apply(q, k, v, self.heads, self.dim_head, self.dim_head ** -0.5)

@@ -394,23 +394,39 @@ def flash_attn_bwd_supported(head_dim: int, Nq: int, Nk: int) -> bool:
     return head_dim in FLASH_BWD_HEAD_DIMS and Nq % 64 == 0 and Nk % 64 == 0
 
 
-def flash_attn_bwd(q, k, v, o, do, lse, heads: int, head_dim: int, scale: float):
-    """Gradients of softmax(q k^T * scale) v for contiguous bf16 [B, N, H*D] tensors, scores never
-    materialised.  Returns (dq, dk, dv)."""
+def flash_attn_bwd(q, k, v, o, do, lse, heads: int, head_dim: int, scale: float, out=None, transposed=None):
+    """Gradients of softmax(q k^T * scale) v, scores never materialised.  q / k / v: bf16 [B, N, H*D], either
+    contiguous or column windows of one packed tensor (equal row and batch strides); o, do contiguous.
+    ``out``: optional (dq, dk, dv) destinations with the strides of q / k / v.  ``transposed``: optional
+    (qt, kt) channel-major [B, H*D, N] views when the caller already holds them.  Returns (dq, dk, dv)."""
     _need_gpu(q, k, v, o, do, lse)
     B, Nq, C = q.shape
     Nk = k.shape[1]
     assert C == heads * head_dim and flash_attn_bwd_supported(head_dim, Nq, Nk)
-    for t in (q, k, v, o, do):
-        assert t.dtype == bf16 and t.is_contiguous() and t.shape[2] == C
+    for t in (q, k, v):
+        assert t.dtype == bf16 and t.stride(2) == 1 and t.shape[2] == C and t.stride(1) == q.stride(1)
+    assert k.stride(0) == v.stride(0) and k.shape == v.shape
+    for t in (o, do):
+        assert t.dtype == bf16 and t.is_contiguous() and t.shape == q.shape
     assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape == (B, heads, Nq)
-    qt, kt, dot = transpose(q), transpose(k), transpose(do)          # [B, C, N]
+    qt, kt = transposed if transposed is not None else (transpose(q), transpose(k))      # [B, C, N]
+    dot = transpose(do)
     delta = torch.empty_like(lse)
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if out is None:
+        dq, dk, dv = (torch.empty(t.shape, dtype=bf16, device=q.device) for t in (q, k, v))
+        assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous(), "strided q / k / v need strided outputs"
+    else:
+        dq, dk, dv = out
+        for g, t in ((dq, q), (dk, k), (dv, v)):
+            assert g.dtype == bf16 and g.shape == t.shape and g.stride() == t.stride()
+    for t in (qt, kt, dot):
+        assert t.dtype == bf16 and t.stride(2) == 1 and t.shape[1] == C
+    assert qt.stride(1) == dot.stride(1)
     check(lib.lbmk_flash_attn_bwd(q.data_ptr(), qt.data_ptr(), k.data_ptr(), kt.data_ptr(), v.data_ptr(),
                                   o.data_ptr(), do.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, head_dim, C,
-                                  Nq, Nk, Nq * C, Nk * C, scale, _stream()), "lbmk_flash_attn_bwd")
+                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, heads, Nq, Nk, head_dim,
+                                  q.stride(1), C, qt.stride(1), kt.stride(1), q.stride(0), k.stride(0), Nq * C,
+                                  qt.stride(0), dot.stride(0), kt.stride(0), scale, _stream()), "lbmk_flash_attn_bwd")
     return dq, dk, dv
 
 

@@ -213,6 +213,42 @@ def test_flash_backward_peaked_rows_and_reproducible(cuda, gen):
         assert rel_l2(a, ref) < tol
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_self_attention_fused_qkv_projection(cuda, gen, flat):
+    """one GEMM for the three projections (stacked weights; a view when they are adjacent in a flat buffer)"""
+    from lbm_amd.models.unets.unet2d_condition import Attention
+    B, N, H, D = 2, 128, 3, 64
+    C = H * D
+    torch.manual_seed(3)
+    att = Attention(C, H, D, None).to(torch.bfloat16)
+    x, res, dy = randbf(gen, B, N, C), randbf(gen, B, N, C), randbf(gen, B, N, C)
+    ws = {n: p.detach().float().requires_grad_() for n, p in att.named_parameters()}
+    xr = x.float().requires_grad_()
+    def heads(t):
+        return t.view(B, N, H, D).transpose(1, 2)
+    q, k, v = (xr @ ws[f"to_{r}.weight"].t() for r in "qkv")
+    orf = F.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(B, N, C)
+    yr = orf @ ws["to_out.0.weight"].t() + ws["to_out.0.bias"] + res.float()
+    yr.backward(dy.float())
+    att = att.to(cuda)
+    if flat:      # re-home the parameters back to back, in reverse order, as the trainer's flat buffers do
+        ps = [att.to_v.weight, att.to_k.weight, att.to_q.weight]
+        buf = torch.cat([p.data.reshape(-1) for p in ps])
+        o = 0
+        for p in ps:
+            p.data = buf[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        stack, cols = att._qkv_stack()
+        assert stack.data_ptr() == buf.data_ptr() and cols == {"v": 0, "k": C, "q": 2 * C}
+    xg = x.to(cuda).requires_grad_()
+    y = att(xg, None, res.to(cuda))
+    assert rel_l2(y, yr) < 8e-3
+    y.backward(dy.to(cuda))
+    assert rel_l2(xg.grad, xr.grad) < 1.5e-2
+    for n, p in att.named_parameters():
+        assert rel_l2(p.grad, ws[n].grad) < 1.5e-2, n
+
+
 @pytest.mark.parametrize("l1", [False, True])
 def test_latent_loss_backward(cuda, gen, l1):
     from lbm_amd.autograd import LatentLossFn
