@@ -228,6 +228,10 @@ int lbmk_im2col_t(const void* x, void* out, int B, int IH, int IW, int OH, int O
  * dx[q][c] = sum over taps and over output pixels p whose tap reads q of dcol[p][tap*Cin + c]; dx NHWC bf16 */
 int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, int OH, int OW, int KH, int KW,
                 int stride, int pad_t, int pad_l, int up2, int Cin, int64_t ld_col, int dx_cs, void* stream);
+/* out[i] = sum_s partial[s][i]: the split-K partial products of a weight-gradient GEMM (f32 [nseg][n],
+ * summed in a fixed order) -> bf16 (out_dtype 0) or f32 (1).  Part of the dW = dY^T X path above. */
+int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream);
+
 /* out[g][n] = sum of x[m][n] over the rows_per_group consecutive rows of group g (bias gradient: one group;
  * time-embedding gradient: one group per image).  x bf16 [rows][ld]; out bf16 (0) / f32 (1) [rows/rows_per_group][N] */
 int64_t lbmk_colsum_scratch_floats(int64_t rows, int64_t rows_per_group, int N);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "lbmk_col2im": (i32, [vp, vp] + [i32] * 12 + [i64, i32, vp]),
     "lbmk_colsum_scratch_floats": (i64, [i64, i64, i32]),
     "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
+    "lbmk_sum_partials": (i32, [vp, vp, i64, i32, i32, vp]),
     "lbmk_groupnorm_bwd_scratch_floats": (i64, [i32, i32, i32, i32]),
     "lbmk_groupnorm_bwd": (i32, [vp] * 9 + [i32] * 5 + [vp]),
     "lbmk_layernorm_bwd_scratch_floats": (i64, [i32, i32]),

@@ -20,6 +20,14 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1, t.shape[-1])
 
 
+def _grad_sink(param):
+    """The trainer's flat-gradient sink of ``param`` when one is accepting direct writes, else None.
+    With a sink, a weight gradient is computed straight into the parameter's slot of the flat gradient
+    buffer (``sink.write``) and the Function returns None for it: no temporary, no accumulation kernel."""
+    ent = getattr(param, "_lbmk_grad_sink", None)
+    return ent if ent is not None and ent.active else None
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b (+ residual) (+ rowvec[image]); ``mod`` supplies the cached packed weights."""
 
@@ -41,7 +49,12 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dy2, ctx.mod.packed_t())[:, :K].reshape(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=weight.dtype)[:N, :K]
+            xc = x2.contiguous() if x2.stride(1) != 1 else x2
+            sink = _grad_sink(ctx.mod.weight)
+            if sink is not None and dy2.shape[1] == N and xc.shape[1] == K:
+                sink.write([ctx.mod.weight], lambda out: ops.gemm_tn(dy2, xc, out=out))
+            else:
+                dw = ops.gemm_tn(dy2, xc, out_dtype=weight.dtype)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy2)[0].to(weight.dtype)
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -86,7 +99,12 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             col_t = ops.im2col_t(x, cin_p, KH, KW, stride, pad, up2, (OH, OW))     # [KH*KW*cin_p, M]
             dwk = ops.gemm_tn_t(ops.transpose(dy2), col_t, out_dtype=torch.float32)   # [npad, KH*KW*cin_p]
-            dw = dwk[:N].reshape(N, KH * KW, cin_p)[:, :, :Cin].permute(0, 2, 1).reshape(N, Cin, KH, KW).to(weight.dtype)
+            dwv = dwk[:N].view(N, KH * KW, cin_p)[:, :, :Cin].permute(0, 2, 1)        # [N, Cin, KH*KW] strided view
+            sink = _grad_sink(ctx.mod.weight)
+            if sink is not None:
+                sink.write([ctx.mod.weight], lambda out: out.view(N, Cin, KH * KW).copy_(dwv))
+            else:
+                dw = dwv.reshape(N, Cin, KH, KW).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy2)[0, :N].to(weight.dtype)
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -258,7 +276,14 @@ class SelfAttnQKVFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear(d2, ctx.mod.packed_qkv_t())[:, :x.shape[-1]].reshape(x.shape)
         dws = [None, None, None]
-        if any(ctx.needs_input_grad[1:4]):
+        mod = ctx.mod
+        ws = [mod.to_q.weight, mod.to_k.weight, mod.to_v.weight]
+        sink = _grad_sink(ws[0])
+        if all(ctx.needs_input_grad[1:4]) and sink is not None and sink.stacked(ws, mod._qkv_stack()[0]):
+            # the three weights are one [3C, K] block of the flat buffer, and so are their gradient slots
+            xc = x2.contiguous() if x2.stride(1) != 1 else x2
+            sink.write(ws, lambda out: ops.gemm_tn(d2, xc, out=out))
+        elif any(ctx.needs_input_grad[1:4]):
             dw = ops.gemm_tn(d2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=ctx.wdt)   # [3C, K]
             dws = [dw[cols[r]:cols[r] + C, :x.shape[-1]] if ctx.needs_input_grad[1 + i] else None
                    for i, r in enumerate("qkv")]

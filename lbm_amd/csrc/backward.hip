@@ -242,6 +242,15 @@ extern "C" int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, in
   return lbmk_check_launch("col2im");
 }
 
+extern "C" int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream) {
+  LBMK_REQUIRE(partial && out && n > 0 && nseg > 0, "sum_partials: n=%lld nseg=%d", (long long)n, nseg);
+  LBMK_REQUIRE(out_dtype == 0 || out_dtype == 1, "sum_partials: out_dtype %d", out_dtype);
+  LBMK_REQUIRE((n + 31) / 32 < (1LL << 31), "sum_partials: grid");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, out, n,
+                     nseg, out_dtype);
+  return lbmk_check_launch("sum_partials");
+}
+
 extern "C" int64_t lbmk_colsum_scratch_floats(int64_t rows, int64_t rows_per_group, int N) {
   if (rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || N <= 0) return -1;
   const int64_t groups = rows / rows_per_group;
@@ -348,18 +357,31 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const bf16_t* __restr
   }
 }
 
-// pass 2a: bc[b][c][2] = sum over slabs
-__global__ void gn_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ bc, int B, int C, int nslab) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over B*C
-  if (i >= (int64_t)B * C) return;
-  const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
+// pass 2a: bc[b][c][2] = sum over slabs.  32 (image, channel) pairs per workgroup, 8 slab lanes per pair with
+// independent loads in flight; the lane sums are added in a fixed order.
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ bc, int B, int C, int nslab) {
+  __shared__ double red[8][32][2];
+  const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + cl;   // over B*C
+  const bool ok = i < (int64_t)B * C;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nslab; ++k) {
-    const float* p = partial + (((int64_t)b * nslab + k) * C + c) * 2;
-    s1 += p[0]; s2 += p[1];
+  if (ok) {
+    const int b = (int)(i / C), c = (int)(i - (int64_t)b * C);
+    for (int k = sl; k < nslab; k += 8) {
+      const float2 p = *(const float2*)(partial + (((int64_t)b * nslab + k) * C + c) * 2);
+      s1 += p.x; s2 += p.y;
+    }
   }
-  bc[i * 2] = (float)s1;
-  bc[i * 2 + 1] = (float)s2;
+  red[sl][cl][0] = s1;
+  red[sl][cl][1] = s2;
+  __syncthreads();
+  if (t < 32 && ok) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a1 += red[k][t][0]; a2 += red[k][t][1]; }
+    bc[i * 2] = (float)a1;
+    bc[i * 2 + 1] = (float)a2;
+  }
 }
 
 // pass 2b: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1;  gsum[b][g] = {sum_c gamma*s1, sum_c gamma*s2} / n
@@ -596,11 +618,15 @@ __global__ void latent_loss_bwd_kernel(const TP* __restrict__ pred, const TZ* __
 
 }  // namespace
 
+// row slabs of the statistics pass: 32 rows each (enough workgroups to fill the chip from 8 images of 32x32 up)
+static int gn_bwd_slabs(int HW) {
+  const int n = (HW + 31) / 32;
+  return n > 256 ? 256 : n;
+}
+
 extern "C" int64_t lbmk_groupnorm_bwd_scratch_floats(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C % 8 || G <= 0 || C % G) return -1;
-  int nslab = (HW + 511) / 512;
-  if (nslab > 256) nslab = 256;
-  return (int64_t)B * nslab * C * 2 + (int64_t)B * C * 2 + (int64_t)B * G * 2;
+  return (int64_t)B * gn_bwd_slabs(HW) * C * 2 + (int64_t)B * C * 2 + (int64_t)B * G * 2;
 }
 
 extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
@@ -610,12 +636,11 @@ extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
   LBMK_REQUIRE(lbmk_groupnorm_bwd_scratch_floats(B, HW, C, G) > 0 && B <= 65535, "groupnorm_bwd: B=%d HW=%d C=%d G=%d", B, HW, C, G);
   LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(dy, 16) && lbmk_aligned(dx, 16), "groupnorm_bwd: misaligned");
   hipStream_t s = (hipStream_t)stream;
-  int nslab = (HW + 511) / 512;
-  if (nslab > 256) nslab = 256;
+  int nslab = gn_bwd_slabs(HW);
   const int rows_per_slab = (HW + nslab - 1) / nslab;
   nslab = (HW + rows_per_slab - 1) / rows_per_slab;
   float* partial = scratch;
-  float* bc = scratch + (int64_t)B * ((HW + 511) / 512 > 256 ? 256 : (HW + 511) / 512) * C * 2;
+  float* bc = scratch + (int64_t)B * gn_bwd_slabs(HW) * C * 2;
   float* gsum = bc + (int64_t)B * C * 2;
   const int nch = C / 8, cpb = nch < 256 ? nch : 256;
   dim3 grid(nslab, (nch + cpb - 1) / cpb, B);
@@ -626,7 +651,7 @@ extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
   else
     hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, grid, dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma,
                        beta, partial, HW, C, G, rows_per_slab, nslab);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(((int64_t)B * C + 255) / 256)), dim3(256), 0, s, partial, bc, B, C, nslab);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(((int64_t)B * C + 31) / 32)), dim3(256), 0, s, partial, bc, B, C, nslab);
   const int nfin = C > B * G ? C : B * G;
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, bc, gamma, dgamma, dbeta, gsum, B, C, G,
                      1.0f / ((float)HW * (float)(C / G)));

@@ -617,11 +617,12 @@ def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torc
     return out
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[n][k] = sum_m a[m][n] * b[m][k]  (weight gradient: a = dY [M, N], b = X or col(X) given
     row-major [M, K], or already transposed via ``b_t`` = [K, M]).  The reduction runs over the rows, so
-    both operands are transposed first and the row range is split across workgroups (split-K)."""
-    return gemm_tn_t(transpose(_pad_rows8(a)), transpose(_pad_rows8(b)), out_dtype)
+    both operands are transposed first and the row range is split across workgroups (split-K).
+    ``out``: contiguous [N, K] destination (e.g. the parameter's slot in a flat gradient buffer)."""
+    return gemm_tn_t(transpose(_pad_rows8(a)), transpose(_pad_rows8(b)), out_dtype, out=out)
 
 
 def _pad_rows8(x: torch.Tensor) -> torch.Tensor:
@@ -631,24 +632,41 @@ def _pad_rows8(x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(x, (0, 0, 0, 8 - r % 8))
 
 
-def gemm_tn_t(a_t: torch.Tensor, b_t: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+def sum_partials(part: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32 [S, ...] -> sum over S in a fixed order, as bf16 or f32."""
+    _need_gpu(part)
+    assert part.dtype == torch.float32 and part.is_contiguous()
+    if out is None:
+        out = torch.empty(part.shape[1:], dtype=out_dtype, device=part.device)
+    assert out.is_contiguous() and out.numel() == part[0].numel() and out.dtype in (bf16, torch.float32)
+    check(lib.lbmk_sum_partials(part.data_ptr(), out.data_ptr(), out.numel(), part.shape[0],
+                                1 if out.dtype == torch.float32 else 0, _stream()), "lbmk_sum_partials")
+    return out
+
+
+def gemm_tn_t(a_t: torch.Tensor, b_t: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[n][k] = sum_m a_t[n][m] * b_t[k][m]; a_t bf16 [N, M], b_t bf16 [K, M] contiguous, M % 8 == 0."""
     _need_gpu(a_t, b_t)
     N, M = a_t.shape
     K = b_t.shape[0]
     assert b_t.shape[1] == M and M % 8 == 0 and a_t.is_contiguous() and b_t.is_contiguous()
+    if out is not None and (tuple(out.shape) != (N, K) or not out.is_contiguous() or out.dtype not in (bf16, torch.float32)):
+        out.copy_(gemm_tn_t(a_t, b_t, torch.float32)[:out.shape[0], :out.shape[1]])
+        return out
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = max(1, min(256 // tiles, M // 1024))
     while S > 1 and (M % S or (M // S) % 8):
         S -= 1
     if S == 1:
+        if out is not None:
+            return gemm_nt(a_t, b_t, out_dtype=out.dtype, out=out)
         return gemm_nt(a_t, b_t, out_dtype=out_dtype)
     ms = M // S
     # chunk s = columns [s*ms, (s+1)*ms) of both operands: batch stride ms, row stride M
     a3 = a_t.as_strided((S, N, ms), (ms, M, 1))
     b3 = b_t.as_strided((S, K, ms), (ms, M, 1))
     part = gemm_nt(a3, b3, out_dtype=torch.float32)
-    return part.sum(0).to(out_dtype)
+    return sum_partials(part, out_dtype, out=out)
 
 
 def im2col_t(x: torch.Tensor, cin: int, KH: int, KW: int, stride: int, pad, up2: bool, out_hw, cin_off: int = 0):

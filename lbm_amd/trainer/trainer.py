@@ -67,36 +67,96 @@ class FlatGroup:
             p.grad = self.grad[o:o + p.numel()].view_as(p)
 
 
+class GradSink:
+    """Direct route for weight gradients: the autograd Functions compute dW straight into the parameter's slot
+    of the flat gradient buffer instead of handing autograd a temporary to accumulate.  Active only inside a
+    trainer step (between ``begin_step`` and ``finish``); a parameter is expected to be used once per step
+    (a second write accumulates, which is only valid while its bucket has not been sent)."""
+
+    def __init__(self, reducer, group):
+        self.reducer, self.group = reducer, group
+        self.slot = {id(p): (o, i) for i, (p, o) in enumerate(zip(group.params, group.offsets))}
+
+    @property
+    def active(self):
+        return self.reducer.active
+
+    def stacked(self, params, stack) -> bool:
+        """True when ``stack`` (a [rows, K] view over the parameters' memory) is one block of the flat buffer"""
+        first = min(params, key=lambda p: p.data_ptr())
+        return (all(id(p) in self.slot for p in params) and stack.data_ptr() == first.data_ptr()
+                and stack.untyped_storage().data_ptr() == self.group.flat.untyped_storage().data_ptr()
+                and stack.numel() == sum(p.numel() for p in params))
+
+    def write(self, params, compute):
+        """compute(out) fills ``out``: the gradient slot of ``params`` (several = one contiguous block, lowest
+        address first)."""
+        first = min(params, key=lambda p: self.slot[id(p)][0])
+        o = self.slot[id(first)][0]
+        n = sum(p.numel() for p in params)
+        rows = sum(p.shape[0] for p in params)
+        out = self.group.grad[o:o + n].view(rows, *first.shape[1:])
+        fresh = [id(p) not in self.reducer.written for p in params]
+        if all(fresh):
+            compute(out)
+        elif not any(fresh):
+            tmp = torch.empty_like(out)
+            compute(tmp)
+            out.add_(tmp)
+        else:
+            raise RuntimeError("stacked parameters must be written together")
+        for p, f in zip(params, fresh):
+            if f:
+                self.reducer.written.add(id(p))
+                self.reducer.param_ready(self.group, self.group.param_bucket[self.slot[id(p)][1]])
+            elif self.reducer.dist is not None:
+                raise RuntimeError("a parameter used twice per step cannot take the direct gradient route under data parallelism")
+
+
 class GradReducer:
     """Bucketed, overlapped data-parallel gradient all-reduce over the flat gradient buffers."""
 
-    def __init__(self, groups: List[FlatGroup], dist=None):
+    def __init__(self, groups: List[FlatGroup], dist=None, direct_grads: bool = True):
         self.groups, self.dist = groups, dist
         self.handles = []
-        self._pending = []
-        if dist is not None:
-            for g in groups:
-                for p, b in zip(g.params, g.param_bucket):
+        self._pending = {}
+        self.active = False
+        self.written = set()
+        for g in groups:
+            sink = GradSink(self, g) if direct_grads else None
+            for p, b in zip(g.params, g.param_bucket):
+                if sink is not None:
+                    p._lbmk_grad_sink = sink
+                if dist is not None:
                     p.register_post_accumulate_grad_hook(self._make_hook(g, b))
+
+    def param_ready(self, group, bucket):
+        """one more parameter of ``bucket`` holds its final gradient: send the bucket when it is complete"""
+        if self.dist is None:
+            return
+        left = self._pending[id(group)]
+        left[bucket] -= 1
+        if left[bucket] == 0:
+            s, e, _ = group.buckets[bucket]
+            self.handles.append(self.dist.all_reduce(group.grad[s:e], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def _make_hook(self, group, bucket):
         def hook(_param):
-            left = self._pending[id(group)]
-            left[bucket] -= 1
-            if left[bucket] == 0:
-                s, e, _ = group.buckets[bucket]
-                self.handles.append(self.dist.all_reduce(group.grad[s:e], op=self.dist.ReduceOp.SUM, async_op=True))
+            self.param_ready(group, bucket)
         return hook
 
     def begin_step(self):
         self.handles = []
+        self.written = set()
         self._pending = {id(g): [c for (_, _, c) in g.buckets] for g in self.groups}
         for g in self.groups:
             g.grad.zero_()
             g.rebind_grads()
+        self.active = True
 
     def finish(self) -> float:
         """Waits for every bucket; returns the factor that turns the summed gradient into the mean."""
+        self.active = False
         if self.dist is None:
             return 1.0
         # parameters that received no gradient this step never fired their hook: reduce what is left
@@ -209,8 +269,13 @@ class TrainingPipeline(nn.Module):
             self.reducer.begin_step()
         else:
             opt.zero_grad(set_to_none=True)
-        out = self.training_step(train_batch, self.global_step)
-        out["loss"].backward()
+        try:
+            out = self.training_step(train_batch, self.global_step)
+            out["loss"].backward()
+        except BaseException:
+            if self.reducer is not None:
+                self.reducer.active = False      # no direct gradient writes outside a step
+            raise
         if self.reducer is not None:
             opt.step(grad_scale=self.reducer.finish())
         else:

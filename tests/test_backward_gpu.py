@@ -411,6 +411,33 @@ def test_training_pipeline_reduces_loss(cuda):
     assert all(lo <= p.data_ptr() < hi for p in grp.params)
 
 
+def test_direct_gradient_route_matches_autograd_accumulation(cuda):
+    """inside a trainer step, weight gradients are written straight into the flat gradient buffer (the stacked
+    q/k/v block in one GEMM); the result equals what autograd's accumulation of returned gradients gives"""
+    from lbm_amd.trainer import TrainingConfig, TrainingPipeline
+    model = _toy_lbm(cuda)
+    pipe = TrainingPipeline(model, TrainingConfig(learning_rate=1e-4, optimizer_name="AdamW", trainable_params=["denoiser.*"]))
+    pipe.configure_optimizers()
+    g = torch.Generator().manual_seed(5)
+    z, zs, eps = (torch.randn(2, 4, 32, 32, generator=g).to(BF).to(cuda) for _ in range(3))
+    ts = torch.tensor([500, 750], device=cuda)
+    grp = pipe.optims[0].groups[0]
+    model.train()
+    # direct route
+    pipe.reducer.begin_step()
+    model({"target": z, "source": zs}, bridge_eps=eps, timesteps=ts)["loss"].backward()
+    pipe.reducer.finish()
+    direct = grp.grad.clone()
+    n_direct = len(pipe.reducer.written)
+    assert n_direct > 0.4 * len(grp.params)       # every convolution / linear weight took it (the rest: biases, norm affines)
+    # plain autograd accumulation onto zeroed gradients (sink inactive outside a step)
+    grp.grad.zero_()
+    grp.rebind_grads()
+    model({"target": z, "source": zs}, bridge_eps=eps, timesteps=ts)["loss"].backward()
+    assert float(direct.float().abs().max()) > 0
+    assert rel_l2(direct, grp.grad) < 1e-6
+
+
 def test_pixel_loss_through_vae_decoder(cuda):
     """pixel loss (l2): gradient w.r.t. the latent through the frozen VAE decoder (incl. the single-head
     d=512 mid attention) against fp32 autograd through the oracle decoder."""
