@@ -27,6 +27,7 @@ extern "C" {
 #define LBMK_ACT_NONE 0
 #define LBMK_ACT_SILU 1
 #define LBMK_ACT_GEGLU 2    /* packed weights interleave 16 value / 16 gate columns */
+#define LBMK_ACT_RELU 3
 
 int lbmk_version(void);
 const char* lbmk_last_error(void);
@@ -272,6 +273,33 @@ int lbmk_pixel_loss_bwd(const void* dec, const void* target, const uint8_t* mask
  * grad_scale multiplies g first (1/world_size after a summing all-reduce). */
 int lbmk_adamw(void* p, const void* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LPIPS perceptual pixel loss (lpips.LPIPS(net="vgg"): src/lbm/models/lbm/lbm_model.py:83, 248-249).  The
+ * VGG16 convolutions are lbmk_igemm launches with LBMK_ACT_RELU; these are the pieces around them.
+ * Activations NHWC bf16; reductions in a fixed order.
+ * ---------------------------------------------------------------------- */
+/* x NCHW [B][3][H][W] (x_dtype 0 bf16 / 1 f32), mask f32 [B][H][W] or NULL -> y NHWC bf16 [B][H][W][8]:
+ * ((clamp ? clip(x,-1,1) : x) * mask - shift3[c]) * inv_scale3[c], channels 3..7 zero (the ScalingLayer). */
+int lbmk_lpips_prep(const void* x, const float* mask, void* y, int B, int H, int W, int x_dtype, int clamp,
+                    const float* shift3, const float* inv_scale3, void* stream);
+int lbmk_lpips_prep_bwd(const void* x, const float* mask, const void* dy, void* dx, int B, int H, int W,
+                        int x_dtype, int clamp, const float* inv_scale3, void* stream);
+/* dx = dy where y > 0 (y = relu output), n elements, n % 8 == 0 */
+int lbmk_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, void* stream);
+/* 2x2 stride-2 max pooling, x [B][H][W][C] -> y [B][H/2][W/2][C]; backward routes dy to the first maximum */
+int lbmk_maxpool2(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int lbmk_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+/* per-layer head: partial[chunk][b] = sum over a chunk of 256 pixels of sum_c w[c] * keep * (n0_c - n1_c)^2,
+ * n = f / (|f|_2 + 1e-10) over channels (normalize_tensor + NetLinLayer + spatial sum); keep: optional
+ * dropout mask, uint8 [B][HW][C], kept elements count twice (nn.Dropout(0.5) of a NetLinLayer in train mode).
+ * lbmk_sum_partials over the chunks, divided by HW, gives the layer's distance per image.  C in 64..512. */
+int64_t lbmk_lpips_head_partial_floats(int B, int HW, int C);
+int lbmk_lpips_head(const void* f0, const void* f1, const float* w, const uint8_t* keep, float* partial,
+                    int B, int HW, int C, void* stream);
+/* df0 = gradient of (gout[b] / HW) * that sum with respect to f0 */
+int lbmk_lpips_head_bwd(const void* f0, const void* f1, const float* w, const uint8_t* keep, const float* gout,
+                        void* df0, int B, int HW, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 LBMK_OK = 0
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_RELU = 0, 1, 2, 3
 DT_BF16, DT_F32 = 0, 1
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -85,6 +85,14 @@ SIGNATURES = {
     "lbmk_colsum_scratch_floats": (i64, [i64, i64, i32]),
     "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "lbmk_sum_partials": (i32, [vp, vp, i64, i32, i32, vp]),
+    "lbmk_lpips_prep": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "lbmk_lpips_prep_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "lbmk_relu_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "lbmk_maxpool2": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "lbmk_maxpool2_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "lbmk_lpips_head_partial_floats": (i64, [i32, i32, i32]),
+    "lbmk_lpips_head": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "lbmk_lpips_head_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "lbmk_groupnorm_bwd_scratch_floats": (i64, [i32, i32, i32, i32]),
     "lbmk_groupnorm_bwd": (i32, [vp] * 9 + [i32] * 5 + [vp]),
     "lbmk_layernorm_bwd_scratch_floats": (i64, [i32, i32]),

@@ -69,19 +69,22 @@ class Conv2dFn(torch.autograd.Function):
     with bias, per-image row vector (time embedding) and residual epilogues."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, rowvec, mod, stride, pad, up2, out_hw):
-        y = ops.conv2d(x, mod.packed(), stride=stride, pad=pad, up2=up2, out_hw=out_hw, rowvec=rowvec, residual=residual)
-        ctx.save_for_backward(x, weight)
-        ctx.mod, ctx.geom = mod, (stride, pad, up2, (y.shape[1], y.shape[2]))
+    def forward(ctx, x, weight, bias, residual, rowvec, mod, stride, pad, up2, out_hw, relu=False):
+        y = ops.conv2d(x, mod.packed(), stride=stride, pad=pad, up2=up2, out_hw=out_hw, rowvec=rowvec, residual=residual,
+                       act=ops.ACT_RELU if relu else ops.ACT_NONE)
+        ctx.save_for_backward(x, weight, *((y,) if relu else ()))
+        ctx.mod, ctx.geom, ctx.relu = mod, (stride, pad, up2, (y.shape[1], y.shape[2])), relu
         ctx.has_bias, ctx.has_res, ctx.has_rv = bias is not None, residual is not None, rowvec is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         stride, pad, up2, (OH, OW) = ctx.geom
         N, Cin, KH, KW = weight.shape
         dy = dy.contiguous()
+        if ctx.relu:
+            dy = ops.relu_bwd(ctx.saved_tensors[2], dy)
         B, IH, IW, Cs = x.shape
         dy2 = _rows(dy)
         npad = dy.shape[-1]          # output channels padded to 8
@@ -111,7 +114,7 @@ class Conv2dFn(torch.autograd.Function):
             dres = dy
         if ctx.has_rv and ctx.needs_input_grad[4]:
             drv = ops.colsum(dy2, OH * OW, out_dtype=bf16)
-        return dx, dw, db, dres, drv, None, None, None, None, None
+        return dx, dw, db, dres, drv, None, None, None, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -288,6 +291,53 @@ class SelfAttnQKVFn(torch.autograd.Function):
             dws = [dw[cols[r]:cols[r] + C, :x.shape[-1]] if ctx.needs_input_grad[1 + i] else None
                    for i, r in enumerate("qkv")]
         return (dx, *dws, None, None, None, None)
+
+
+class MaxPool2Fn(torch.autograd.Function):
+    """2x2 / stride-2 max pooling on NHWC"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool2(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, dy.contiguous())
+
+
+class LpipsPrepFn(torch.autograd.Function):
+    """LPIPS input stage: optional clamp to [-1, 1], valid-pixel mask, ScalingLayer, NCHW -> NHWC bf16."""
+
+    @staticmethod
+    def forward(ctx, x, mask, shift, scale, clamp):
+        x = x.contiguous()
+        ctx.save_for_backward(x, mask if mask is not None else torch.empty(0))
+        ctx.cfg = (mask is not None, tuple(scale), clamp)
+        return ops.lpips_prep(x, mask, shift, scale, clamp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mask = ctx.saved_tensors
+        has_mask, scale, clamp = ctx.cfg
+        return ops.lpips_prep_bwd(x, mask if has_mask else None, dy.contiguous(), scale, clamp), None, None, None, None
+
+
+class LpipsHeadFn(torch.autograd.Function):
+    """one LPIPS layer: unit-normalise both feature maps over channels, squared difference, 1x1 linear head
+    with non-trainable weights here (gradient to the first feature map only), spatial mean -> [B]."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, w, keep):
+        ctx.save_for_backward(f0, f1, w, keep if keep is not None else torch.empty(0))
+        ctx.has_keep = keep is not None
+        return ops.lpips_head(f0, f1, w, keep)
+
+    @staticmethod
+    def backward(ctx, gout):
+        f0, f1, w, keep = ctx.saved_tensors
+        return ops.lpips_head_bwd(f0, f1, w, keep if ctx.has_keep else None, gout), None, None, None
 
 
 class NchwToNhwcFn(torch.autograd.Function):

@@ -110,6 +110,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           v[e] = acc[i][j][e];
           if (geglu) v[e] *= gelu_erf_f(acc[i][(j + 1) % NI][e]);
           else if (p.act == LBMK_ACT_SILU) v[e] = silu_f(v[e]);
+          else if (p.act == LBMK_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.out_f32) {
           float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
@@ -177,6 +178,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
         if (rowvec) val += bf2f(rowvec[(int64_t)bimg * p.rowvec_ld + no + e]);
         if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
         if (p.act == LBMK_ACT_SILU) val = silu_f(val);
+        if (p.act == LBMK_ACT_RELU) val = fmaxf(val, 0.f);
         if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
         else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
       }
@@ -505,7 +507,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE(d.IH > 0 && d.IW > 0 && d.OH > 0 && d.OW > 0 && d.stride >= 1, "igemm: spatial dims");
   LBMK_REQUIRE(d.M % (d.OH * d.OW) == 0, "igemm: M=%d is not a whole number of %dx%d images", d.M, d.OH, d.OW);
   LBMK_REQUIRE((int64_t)(d.M / (d.OH * d.OW)) * d.IH * d.IW < (1LL << 31), "igemm: input pixel count overflows int32");
-  LBMK_REQUIRE(d.act >= 0 && d.act <= 2, "igemm: act %d", d.act);
+  LBMK_REQUIRE(d.act >= 0 && d.act <= 3, "igemm: act %d", d.act);
   LBMK_REQUIRE(d.k_order == 0 || (d.k_order == 1 && d.Cin % 64 == 0), "igemm: k_order %d needs Cin %% 64 == 0", d.k_order);
   LBMK_REQUIRE(d.ldo >= (d.act == LBMK_ACT_GEGLU ? d.N / 2 : d.N), "igemm: ldo=%d too small", d.ldo);
   LBMK_REQUIRE(lbmk_aligned(d.out, d.out_f32 ? 16 : 8), "igemm: out misaligned");

@@ -63,14 +63,15 @@ class HipConv2d(nn.Conv2d, _Cached):
     def forward(self, x, *, up2=False, rowvec=None, residual=None, act=ops.ACT_NONE):
         s = self.stride[0]
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            if act != ops.ACT_NONE:
-                raise NotImplementedError("fused activations are inference-only; apply the activation as its own op when training")
+            if act not in (ops.ACT_NONE, ops.ACT_RELU):
+                raise NotImplementedError("fused SiLU / GEGLU are inference-only; apply the activation as its own op when training")
             from ..autograd import Conv2dFn
+            relu = act == ops.ACT_RELU
             if self.asym_pad:
                 return Conv2dFn.apply(x, self.weight, self.bias, residual, rowvec, self, s, (0, 0), False,
-                                      (x.shape[1] // 2, x.shape[2] // 2))
+                                      (x.shape[1] // 2, x.shape[2] // 2), relu)
             return Conv2dFn.apply(x, self.weight, self.bias, residual, rowvec, self, s,
-                                  (self.padding[0], self.padding[1]), up2, None)
+                                  (self.padding[0], self.padding[1]), up2, None, relu)
         if self.asym_pad:
             out_hw = (x.shape[1] // 2, x.shape[2] // 2)
             return ops.conv2d(x, self.packed(), stride=s, pad=(0, 0), out_hw=out_hw, rowvec=rowvec,

@@ -53,7 +53,11 @@ class LBMModel(BaseModel):
         self.mask_key = config.mask_key
         self.bridge_noise_sigma = config.bridge_noise_sigma
         self.num_iterations = nn.Parameter(torch.tensor(0, dtype=torch.float32), requires_grad=False)
-        self.lpips_loss = None
+        if self.pixel_loss_type == "lpips" and self.pixel_loss_weight > 0:
+            from ..lpips import LPIPS
+            self.lpips_loss = LPIPS(net="vgg")           # lbm_model.py:82-83; weights come with the checkpoint
+        else:
+            self.lpips_loss = None
 
     def on_fit_start(self, device: torch.device | None = None, *args, **kwargs):
         super().on_fit_start(device=device, *args, **kwargs)
@@ -66,10 +70,6 @@ class LBMModel(BaseModel):
     def forward(self, batch: Dict[str, Any], step=0, batch_idx=0, *args, bridge_eps: Optional[torch.Tensor] = None,
                 timesteps: Optional[torch.Tensor] = None, **kwargs):
         self.num_iterations += 1
-        if self.pixel_loss_weight > 0 and self.pixel_loss_type == "lpips":
-            raise NotImplementedError("the LPIPS pixel loss needs the lpips package's VGG weights, which are not available offline; "
-                                      "pixel_loss_type 'l2' / 'l1' run on the HIP path")
-
         if self.vae is not None:
             z = self.vae.encode(batch[self.target_key])
             downsampling_factor = self.vae.downsampling_factor
@@ -147,7 +147,7 @@ class LBMModel(BaseModel):
                                l1=self.latent_loss_type == "l1")
 
     def pixel_loss(self, prediction, model_input, valid_mask, offsets=None):
-        """Random crop to ``pixel_loss_max_size``, decode, clamp, l2 / l1 against the target pixels
+        """Random crop to ``pixel_loss_max_size``, decode, clamp, l2 / l1 / LPIPS against the target pixels
         (lbm_model.py:197-249; crop offsets are drawn on the host in the reference's order).
         ``offsets=(offset_h, offset_w)`` overrides the draw (tests)."""
         f = self.vae.downsampling_factor if self.vae is not None else 1
@@ -169,8 +169,14 @@ class LBMModel(BaseModel):
         if valid_mask is not None:
             valid_mask = valid_mask[:, :, sl_h, sl_w]
         decoded = self.vae.decode(prediction) if self.vae is not None else prediction
+        if self.pixel_loss_type == "lpips":
+            # lpips_loss(clamp(decoded) * mask, target * mask).mean() (lbm_model.py:248-249); clamp and mask are fused
+            # into the network's input stage
+            if self.lpips_loss is None:
+                raise NotImplementedError("pixel_loss_type 'lpips' needs pixel_loss_weight > 0 at construction")
+            return self.lpips_loss(decoded, model_input, mask=valid_mask, clamp0=True).mean()
         if self.pixel_loss_type not in ("l2", "l1"):
-            raise NotImplementedError(f"pixel loss type {self.pixel_loss_type} is not available on the HIP path")
+            raise NotImplementedError(f"pixel loss type {self.pixel_loss_type} not implemented")
         from ...autograd import PixelLossFn
         return PixelLossFn.apply(decoded.contiguous(), model_input, valid_mask, self.pixel_loss_type == "l1")
 

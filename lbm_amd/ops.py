@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _C
-from ._C import ACT_GEGLU, ACT_NONE, ACT_SILU, DT_BF16, DT_F32, IgemmDesc, check, lib
+from ._C import ACT_GEGLU, ACT_NONE, ACT_RELU, ACT_SILU, DT_BF16, DT_F32, IgemmDesc, check, lib
 
 bf16 = torch.bfloat16
 
@@ -836,3 +836,96 @@ def pixel_loss_bwd(dec, target, mask, gout, l1: bool):
 def scale_rows(y, a):
     """out[b] = a[b] * y[b] in f32 (a: f32 [B])"""
     return axpy_rows(torch.zeros_like(y), y, a)
+
+
+# --------------------------------------------------------------------------------------
+# LPIPS pieces (the VGG convolutions are conv2d(..., act=ACT_RELU))
+# --------------------------------------------------------------------------------------
+def _f32x3(v):
+    return (C.c_float * 3)(*[float(a) for a in v])
+
+
+def _mask_f32(mask, B, H, W):
+    if mask is None:
+        return None
+    m = mask.to(torch.float32).expand(B, 1, H, W).contiguous()
+    return m
+
+
+def lpips_prep(x: torch.Tensor, mask, shift, scale, clamp: bool) -> torch.Tensor:
+    """NCHW [B, 3, H, W] (bf16 / f32) -> NHWC bf16 [B, H, W, 8]: ((clip(x) if clamp else x) * mask - shift) / scale."""
+    _need_gpu(x)
+    assert x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous() and x.dtype in (bf16, torch.float32)
+    B, _, H, W = x.shape
+    m = _mask_f32(mask, B, H, W)
+    y = torch.empty(B, H, W, 8, dtype=bf16, device=x.device)
+    check(lib.lbmk_lpips_prep(x.data_ptr(), _ptr(m), y.data_ptr(), B, H, W, 1 if x.dtype == torch.float32 else 0,
+                              1 if clamp else 0, _f32x3(shift), _f32x3([1.0 / s for s in scale]), _stream()), "lbmk_lpips_prep")
+    return y
+
+
+def lpips_prep_bwd(x, mask, dy, scale, clamp: bool) -> torch.Tensor:
+    _need_gpu(x, dy)
+    B, _, H, W = x.shape
+    assert dy.dtype == bf16 and dy.is_contiguous() and tuple(dy.shape) == (B, H, W, 8)
+    m = _mask_f32(mask, B, H, W)
+    dx = torch.empty_like(x)
+    check(lib.lbmk_lpips_prep_bwd(x.data_ptr(), _ptr(m), dy.data_ptr(), dx.data_ptr(), B, H, W,
+                                  1 if x.dtype == torch.float32 else 0, 1 if clamp else 0,
+                                  _f32x3([1.0 / s for s in scale]), _stream()), "lbmk_lpips_prep_bwd")
+    return dx
+
+
+def relu_bwd(y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _need_gpu(y, dy)
+    assert y.dtype == bf16 and dy.dtype == bf16 and y.is_contiguous() and dy.is_contiguous() and y.shape == dy.shape
+    dx = torch.empty_like(y)
+    check(lib.lbmk_relu_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "lbmk_relu_bwd")
+    return dx
+
+
+def maxpool2(x: torch.Tensor) -> torch.Tensor:
+    """NHWC bf16 [B, H, W, C] -> [B, H/2, W/2, C]"""
+    _need_gpu(x)
+    assert x.dtype == bf16 and x.dim() == 4 and x.is_contiguous()
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, H // 2, W // 2, Cc, dtype=bf16, device=x.device)
+    check(lib.lbmk_maxpool2(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _stream()), "lbmk_maxpool2")
+    return y
+
+
+def maxpool2_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x, dy)
+    B, H, W, Cc = x.shape
+    assert dy.dtype == bf16 and dy.is_contiguous() and tuple(dy.shape) == (B, H // 2, W // 2, Cc)
+    dx = torch.empty_like(x)
+    check(lib.lbmk_maxpool2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _stream()), "lbmk_maxpool2_bwd")
+    return dx
+
+
+def lpips_head(f0: torch.Tensor, f1: torch.Tensor, w: torch.Tensor, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f0, f1: NHWC bf16 feature maps, w: f32 [C] -> f32 [B]: spatial mean of sum_c w_c (n0_c - n1_c)^2."""
+    _need_gpu(f0, f1, w)
+    assert f0.dtype == bf16 and f1.dtype == bf16 and f0.is_contiguous() and f1.is_contiguous() and f0.shape == f1.shape
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == f0.shape[-1]
+    B, Cc = f0.shape[0], f0.shape[-1]
+    HW = f0.numel() // (B * Cc)
+    assert keep is None or (keep.dtype == torch.uint8 and keep.is_contiguous() and keep.numel() == f0.numel())
+    nfl = lib.lbmk_lpips_head_partial_floats(B, HW, Cc)
+    if nfl <= 0:
+        raise _C.LbmkError(f"lpips_head: B={B} HW={HW} C={Cc}")
+    part = torch.empty(nfl // B, B, dtype=torch.float32, device=f0.device)
+    check(lib.lbmk_lpips_head(f0.data_ptr(), f1.data_ptr(), w.data_ptr(), _ptr(keep), part.data_ptr(), B, HW, Cc, _stream()),
+          "lbmk_lpips_head")
+    return sum_partials(part) * (1.0 / HW)
+
+
+def lpips_head_bwd(f0, f1, w, keep, gout: torch.Tensor) -> torch.Tensor:
+    _need_gpu(f0, f1, w, gout)
+    B, Cc = f0.shape[0], f0.shape[-1]
+    HW = f0.numel() // (B * Cc)
+    g = gout.to(torch.float32).reshape(B).contiguous()
+    df0 = torch.empty_like(f0)
+    check(lib.lbmk_lpips_head_bwd(f0.data_ptr(), f1.data_ptr(), w.data_ptr(), _ptr(keep), g.data_ptr(), df0.data_ptr(),
+                                  B, HW, Cc, _stream()), "lbmk_lpips_head_bwd")
+    return df0

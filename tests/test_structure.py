@@ -221,3 +221,20 @@ def test_unet2d_refine_parameter_count_from_first_principles():
               "up_blocks.2.upsamplers.0.conv.weight", "conv_norm_out.bias", "conv_out.weight"]:
         assert k in keys, k
     assert "down_blocks.3.downsamplers.0.conv.weight" not in keys and "up_blocks.3.upsamplers.0.conv.weight" not in keys
+
+
+def test_lpips_module_tree_matches_the_package_layout():
+    """state-dict keys and parameter count of lpips.LPIPS(net="vgg") (14,714,688 VGG16 feature parameters + 1,472
+    head weights; the heads appear as lin{k} and again inside the lins ModuleList)"""
+    from lbm_amd.models.lpips import LPIPS
+    m = LPIPS()
+    keys = set(m.state_dict().keys())
+    assert len(keys) == 38
+    for k in ("scaling_layer.shift", "scaling_layer.scale", "net.slice1.0.weight", "net.slice1.2.bias", "net.slice2.5.weight",
+              "net.slice2.7.weight", "net.slice3.10.weight", "net.slice3.14.bias", "net.slice4.17.weight", "net.slice4.21.weight",
+              "net.slice5.24.weight", "net.slice5.28.bias", "lin0.model.1.weight", "lin4.model.1.weight", "lins.0.model.1.weight",
+              "lins.4.model.1.weight"):
+        assert k in keys, k
+    assert sum(p.numel() for p in m.parameters()) == 14_716_160
+    assert m.lin2.model[1].weight.shape == (1, 256, 1, 1) and m.lins[2] is m.lin2
+    assert not m.training and all(not p.requires_grad for p in m.net.parameters())
