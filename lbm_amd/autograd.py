@@ -194,10 +194,16 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, heads, dim_head, scale):
-        if k.shape[1] % 8 or q.shape[1] % 8:
-            raise NotImplementedError("training attention needs token counts that are multiples of 8")
+        if q.shape[1] % 8:
+            raise NotImplementedError("training attention needs a query token count that is a multiple of 8")
         ctx.cfg = (heads, dim_head, scale)
-        if (ops.flash_attn_bwd_supported(dim_head, q.shape[1], k.shape[1]) and q.is_contiguous()
+        Nk = k.shape[1]
+        ctx.nk = Nk
+        if Nk % 8:
+            # a handful of context tokens (lighting parameters): zero rows up to a multiple of 8, masked out of the softmax
+            k = torch.nn.functional.pad(k, (0, 0, 0, -Nk % 8))
+            v = torch.nn.functional.pad(v, (0, 0, 0, -Nk % 8))
+        elif (ops.flash_attn_bwd_supported(dim_head, q.shape[1], Nk) and q.is_contiguous()
                 and k.is_contiguous() and v.is_contiguous()):
             # fused backward available: keep the output and the row log-sum-exp instead of recomputing P
             o, lse = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale, return_lse=True)
@@ -206,16 +212,22 @@ class AttentionFn(torch.autograd.Function):
             return o
         ctx.fused = False
         if dim_head in (40, 64, 80, 160):
-            o = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale)
+            o = ops.flash_attn(q, k[:, :Nk], ops.transpose(v), heads, dim_head, scale)     # keys past Nk are masked
         else:
             # head dims without a flash kernel (VAE mid block: one head of 512): materialised scores
             B, Nq, C = q.shape
-            p = ops.softmax_rows(ops.gemm_nt(_heads(q, heads, dim_head), _heads(k, heads, dim_head),
-                                             out_dtype=torch.float32, alpha=scale))
+            p = ops.softmax_rows(AttentionFn._scores(q, k, heads, dim_head, scale, Nk))
             o = torch.empty_like(q)
             ops.gemm_nt(p, ops.transpose(v).view(B, heads, dim_head, k.shape[1]), out=_heads(o, heads, dim_head))
         ctx.save_for_backward(q, k, v)
         return o
+
+    @staticmethod
+    def _scores(q, k, H, D, scale, nk):
+        s = ops.gemm_nt(_heads(q, H, D), _heads(k, H, D), out_dtype=torch.float32, alpha=scale)
+        if nk < k.shape[1]:
+            s[..., nk:] = float("-inf")
+        return s
 
     @staticmethod
     def backward(ctx, do):
@@ -229,7 +241,7 @@ class AttentionFn(torch.autograd.Function):
         Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         q4, k4, v4, do4 = (_heads(t, H, D) for t in (q, k, v, do))
-        p = ops.softmax_rows(ops.gemm_nt(q4, k4, out_dtype=torch.float32, alpha=scale))     # [B, H, Nq, Nk] bf16
+        p = ops.softmax_rows(AttentionFn._scores(q, k, H, D, scale, ctx.nk))                 # [B, H, Nq, Nk] bf16
         # channel-major copies: [B, C, N] read as [B, H, D, N]
         qt4 = ops.transpose(q).view(B, H, D, Nq)
         kt4 = ops.transpose(k).view(B, H, D, Nk)
@@ -241,7 +253,7 @@ class AttentionFn(torch.autograd.Function):
         ops.gemm_nt(ds, kt4, out=_heads(dq, H, D))                                           # dQ = dS K
         dst = ops.transpose(ds.view(B * H, Nq, Nk)).view(B, H, Nk, Nq)
         ops.gemm_nt(dst, qt4, out=_heads(dk, H, D))                                          # dK = dS^T Q
-        return dq, dk, dv, None, None, None
+        return dq, dk[:, :ctx.nk], dv[:, :ctx.nk], None, None, None
 
 
 class SelfAttnQKVFn(torch.autograd.Function):

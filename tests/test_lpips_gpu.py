@@ -155,3 +155,47 @@ def test_lbm_forward_with_lpips_pixel_loss(cuda):
     grads = [p.grad for p in model.denoiser.parameters()]
     assert all(gd is not None and torch.isfinite(gd.float()).all() for gd in grads)
     assert all(p.grad is None for n, p in model.lpips_loss.named_parameters() if n.startswith("net."))
+
+
+def test_refine_unet_gradients_and_lpips_training_step(cuda):
+    """the pixel-space refine denoiser (UNet2DModel, vae=None): parameter gradients against autograd through the fp32
+    restatement, then one trainer step of the refine model with the LPIPS pixel loss (the shipped refine configs)."""
+    from lbm_amd.models.unets import DiffusersUNet2DWrapper
+    from lbm_amd.inference.relight import build_filllight_refine_model
+    from lbm_amd.trainer import TrainingConfig, TrainingPipeline
+    from oracle import diffusers_ref as dr
+    from test_models_gpu import SMALL_UNET2D
+    torch.manual_seed(3)
+    m = DiffusersUNet2DWrapper(**SMALL_UNET2D).to(BF)
+    sd = {k: v.detach().float().clone().requires_grad_() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    x, rgb, dy = (torch.randn(2, 3, 64, 64, generator=g).to(BF) for _ in range(3))
+    ts = torch.tensor([1000.0, 500.0])
+    ref = dr.unet2d_forward(sd, SMALL_UNET2D, torch.cat([x, rgb], 1).float(), ts)
+    ref.backward(dy.float())
+    m = m.to(cuda).train()
+    out = m(sample=x.to(cuda), timestep=ts.to(cuda), conditioning={"cond": {"concat": rgb.to(cuda)}})
+    assert rel_l2(out, ref) < 1e-2
+    out.backward(dy.to(cuda))
+    num = den = 0.0
+    for name, p in m.named_parameters():
+        assert p.grad is not None, name
+        a, b = p.grad.detach().float().cpu(), sd[name].grad
+        num += float((a - b).pow(2).sum())
+        den += float(b.pow(2).sum())
+    assert (num / den) ** 0.5 < 6e-2
+
+    model = build_filllight_refine_model(backbone_signature="offline", block_out_channels=[64, 64, 128], pixel_loss_type="lpips",
+                                         pixel_loss_weight=1.0, bridge_noise_sigma=0.005)
+    _randomise(model.lpips_loss)
+    model = model.to(BF).to(cuda)
+    pipe = TrainingPipeline(model, TrainingConfig(learning_rate=1e-4, optimizer_name="AdamW", trainable_params=["denoiser.*"]))
+    pipe.configure_optimizers()
+    assert all(not p.requires_grad for p in model.lpips_loss.parameters())
+    model.train()
+    batch = {"source": (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(BF).to(cuda),
+             "target": (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(BF).to(cuda)}
+    batch["rgb"] = batch["source"]
+    losses = [float(pipe.fit_step(batch)["loss"]) for _ in range(3)]
+    assert all(l == l and l > 0 for l in losses)
+    assert pipe.global_step == 3
