@@ -20,6 +20,7 @@ class GaussianFourierFeatures(nn.Module):
         self.register_buffer("B", torch.randn(mapping_size, in_features) * scale)
 
     def forward(self, x):
+        x = x.to(self.B.dtype)      # the reference runs this product under autocast; without it dtypes must agree
         x_proj = 2 * torch.pi * x @ self.B.T
         return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
 
