@@ -229,6 +229,12 @@ int lbmk_im2col_t(const void* x, void* out, int B, int IH, int IW, int OH, int O
  * dx[q][c] = sum over taps and over output pixels p whose tap reads q of dcol[p][tap*Cin + c]; dx NHWC bf16 */
 int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, int OH, int OW, int KH, int KW,
                 int stride, int pad_t, int pad_l, int up2, int Cin, int64_t ld_col, int dx_cs, void* stream);
+/* Convolution parameter bf16 [N][Cin][KH][KW] -> GEMM operand bf16 [n_p][Kp] in lbmk_igemm's K order (k_order as in
+ * lbmk_igemm_desc; channel count padded to 8, zero fill).  swap_flip = 1 packs the input-gradient filter: rows are
+ * the input channels, K runs over (mirrored tap, output channel).  Done once per optimizer step per layer. */
+int lbmk_pack_conv_weight(const void* w, void* out, int N, int Cin, int KH, int KW, int n_p, int Kp,
+                          int k_order, int swap_flip, void* stream);
+
 /* out[i] = sum_s partial[s][i]: the split-K partial products of a weight-gradient GEMM (f32 [nseg][n],
  * summed in a fixed order) -> bf16 (out_dtype 0) or f32 (1).  Part of the dW = dY^T X path above. */
 int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream);

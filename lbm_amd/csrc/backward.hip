@@ -876,3 +876,50 @@ extern "C" int lbmk_pixel_loss_bwd(const void* dec, const void* target, const ui
 #undef PLB
   return lbmk_check_launch("pixel_loss_bwd");
 }
+
+// ---- convolution weight packing ---------------------------------------------------------------------
+// [Cout][Cin][KH][KW] parameter -> the GEMM operand [n_p][Kp] with k = tap * cin_p + c (k_order 0) or
+// k = (c / 64) * ntaps * 64 + tap * 64 + c % 64 (k_order 1), zero padded.  swap_flip: the input-gradient
+// filter instead (rows = input channels, columns over output channels, taps mirrored).
+namespace {
+__global__ void pack_conv_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int KH,
+                                        int KW, int rows, int cols, int cols_p, int n_p, int Kp, int k_order, int swap_flip) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)n_p * Kp) return;
+  const int r = (int)(i / Kp), k = (int)(i - (int64_t)r * Kp);
+  const int ntaps = KH * KW;
+  bf16_t v = 0;
+  if (r < rows && k < ntaps * cols_p) {
+    int tap, c;
+    if (k_order) {
+      const int chunk = k / (ntaps * 64), rem = k - chunk * ntaps * 64;
+      tap = rem >> 6;
+      c = chunk * 64 + (rem & 63);
+    } else {
+      tap = k / cols_p;
+      c = k - tap * cols_p;
+    }
+    if (c < cols) {
+      const int kh = tap / KW, kw = tap - kh * KW;
+      if (swap_flip) v = w[(((int64_t)c * Cin + r) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];   // w[out c][in r]
+      else v = w[(((int64_t)r * Cin + c) * KH + kh) * KW + kw];
+    }
+  }
+  out[i] = v;
+}
+}  // namespace
+
+extern "C" int lbmk_pack_conv_weight(const void* w, void* out, int N, int Cin, int KH, int KW, int n_p, int Kp,
+                                     int k_order, int swap_flip, void* stream) {
+  LBMK_REQUIRE(w && out && N > 0 && Cin > 0 && KH > 0 && KW > 0, "pack_conv_weight: arguments");
+  const int rows = swap_flip ? Cin : N, cols = swap_flip ? N : Cin;
+  const int cols_p = (cols + 7) / 8 * 8;
+  LBMK_REQUIRE(n_p >= rows && n_p % 8 == 0 && Kp >= KH * KW * cols_p && Kp % 8 == 0, "pack_conv_weight: n_p=%d Kp=%d", n_p, Kp);
+  LBMK_REQUIRE(!k_order || cols_p % 64 == 0, "pack_conv_weight: k_order 1 needs whole 64-channel chunks");
+  const int64_t total = (int64_t)n_p * Kp;
+  LBMK_REQUIRE((total + 255) / 256 < (1LL << 31), "pack_conv_weight: grid");
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)w, (bf16_t*)out, N, Cin, KH, KW, rows, cols, cols_p, n_p, Kp, k_order, swap_flip);
+  return lbmk_check_launch("pack_conv_weight");
+}
+

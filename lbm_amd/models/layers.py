@@ -47,8 +47,7 @@ class HipConv2d(nn.Conv2d, _Cached):
 
     def packed_dgrad(self) -> ops.PackedWeight:
         """input-gradient filter of a stride-1 convolution: in/out channels swapped, taps flipped"""
-        return self._cached("d", (self.weight,),
-                            lambda: ops.pack_conv_weight(self.weight.permute(1, 0, 2, 3).flip(2, 3).contiguous(), None))
+        return self._cached("d", (self.weight,), lambda: ops.pack_conv_weight_dgrad(self.weight))
 
     def packed_col_t(self) -> ops.PackedWeight:
         """[KH*KW*Cin_p, Cout_p] matrix (tap-major rows): dcol = dY . W for the col2im input gradient"""

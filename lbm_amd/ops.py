@@ -72,6 +72,8 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pack
     n_p = ceil_to(N, 8)
     K = KH * KW * cin_p
     Kp = ceil_to(K, 64)
+    if weight.is_cuda and weight.dtype == bf16 and weight.is_contiguous():
+        return _pack_conv_weight_dev(weight.detach(), bias, False)
     w = torch.zeros(N, KH * KW, cin_p, dtype=bf16, device=weight.device)
     w[:, :, :Cin] = weight.detach().permute(0, 2, 3, 1).reshape(N, KH * KW, Cin).to(bf16)
     # 3x3 layers with whole 64-channel chunks: make the 9 taps of one chunk consecutive K tiles, so
@@ -86,6 +88,31 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pack
         b = torch.zeros(n_p, dtype=torch.float32, device=weight.device)
         b[:N] = bias.detach().float()
     return PackedWeight(packed.contiguous(), b, n_p, K, Kp, cin_p, KH, KW, alg_nk=N * KH * KW * Cin, k_order=k_order)
+
+
+def _pack_conv_weight_dev(weight: torch.Tensor, bias: Optional[torch.Tensor], dgrad: bool) -> PackedWeight:
+    """one kernel: the forward operand, or (``dgrad``) the input-gradient filter (channels swapped, taps mirrored)"""
+    N, Cin, KH, KW = weight.shape
+    rows, cols = (Cin, N) if dgrad else (N, Cin)
+    cols_p, rows_p = ceil_to(cols, 8), ceil_to(rows, 8)
+    K = KH * KW * cols_p
+    Kp = ceil_to(K, 64)
+    k_order = 1 if (KH * KW > 1 and cols_p % 64 == 0) else 0
+    packed = torch.empty(rows_p, Kp, dtype=bf16, device=weight.device)
+    check(lib.lbmk_pack_conv_weight(weight.data_ptr(), packed.data_ptr(), N, Cin, KH, KW, rows_p, Kp, k_order,
+                                    1 if dgrad else 0, _stream()), "lbmk_pack_conv_weight")
+    b = None
+    if bias is not None:
+        b = torch.zeros(rows_p, dtype=torch.float32, device=weight.device)
+        b[:rows] = bias.detach().float()
+    return PackedWeight(packed, b, rows_p, K, Kp, cols_p, KH, KW, alg_nk=rows * KH * KW * cols, k_order=k_order)
+
+
+def pack_conv_weight_dgrad(weight: torch.Tensor) -> PackedWeight:
+    """input-gradient filter of a stride-1 convolution: in/out channels swapped, taps flipped"""
+    if weight.is_cuda and weight.dtype == bf16 and weight.is_contiguous():
+        return _pack_conv_weight_dev(weight.detach(), None, True)
+    return pack_conv_weight(weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous(), None)
 
 
 def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:

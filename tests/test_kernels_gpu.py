@@ -430,3 +430,18 @@ def test_flash_attn_small_head_dims(ops, cuda, gen, D, H, N):
         return t.float().view(B, N, H, D).transpose(1, 2)
     ref = F.scaled_dot_product_attention(heads(q), heads(k), heads(v)).transpose(1, 2).reshape(B, N, H * D)
     assert rel_l2(o, ref) < 6e-3
+
+
+@pytest.mark.parametrize("N,Cin,k", [(64, 3, 3), (4, 128, 3), (320, 320, 3), (640, 320, 1), (128, 192, 3), (24, 40, 3)])
+def test_pack_conv_weight_kernel_matches_host_packing(ops, cuda, gen, N, Cin, k):
+    """device packing (forward operand and input-gradient filter) is bit-identical to the torch-side re-layout"""
+    w = torch.randn(N, Cin, k, k, generator=gen).bfloat16()
+    b = torch.randn(N, generator=gen).bfloat16()
+    ref = ops.pack_conv_weight(w, b)                                   # CPU tensors: host route
+    dev = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
+    assert (dev.N, dev.K, dev.Kp, dev.Cin, dev.k_order, dev.alg_nk) == (ref.N, ref.K, ref.Kp, ref.Cin, ref.k_order, ref.alg_nk)
+    assert torch.equal(dev.w.cpu(), ref.w) and torch.equal(dev.bias.cpu(), ref.bias)
+    refd = ops.pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), None)
+    devd = ops.pack_conv_weight_dgrad(w.to(cuda))
+    assert (devd.N, devd.K, devd.Kp, devd.Cin, devd.k_order, devd.alg_nk) == (refd.N, refd.K, refd.Kp, refd.Cin, refd.k_order, refd.alg_nk)
+    assert torch.equal(devd.w.cpu(), refd.w)
