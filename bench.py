@@ -85,6 +85,20 @@ def cpu_baseline(model, threads):
                       f"~{n / dt * 5.33 / 23.25:.3f} images/s extrapolated by FLOPs)"}
 
 
+def pmc_traffic(args):
+    """HBM bytes per igemm launch from the committed rocprofv3 --pmc passes over this same command (counters cannot
+    be read from inside the run); None when the workload differs from the profiled one or the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_igemm_step_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if rec.get("workload") != {"res": args.res, "batch": args.batch, "nfe": args.nfe}:
+        return None
+    return round(rec["traffic_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +151,7 @@ def main():
         tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args),
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
                     "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3)}
