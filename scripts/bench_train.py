@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Training-step benchmark (BASELINE config 4): 512x512 images, batch 8 per GPU, bf16, SDXL-style UNet:
+"""Training-step benchmark: 512x512 images, batch 8 per GPU, bf16, SDXL-style UNet:
 two frozen VAE encodes (forward only) + bridge interpolant + UNet forward/backward + latent loss + gradient
 all-reduce (RCCL, N > 1) + fused AdamW.  7.31 TFLOP per sample (2*1.117 + 3*1.693).
 

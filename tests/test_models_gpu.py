@@ -354,3 +354,23 @@ def test_refine_model_builder_and_sampling(cuda):
     src = (torch.rand(1, 3, 64, 64, generator=g) * 2 - 1).to(BF).to(cuda)
     out = model.sample(src, num_steps=2, conditioner_inputs={"rgb": src})
     assert out.shape == (1, 3, 64, 64) and torch.isfinite(out.float()).all()
+
+
+def test_full_size_pipeline_is_batch_consistent(cuda):
+    """the headline workload's size (1024x1024, the 2.43 B-parameter UNet, SD VAE): an image gives the same output
+    alone and as a member of a batch.  Tile shapes (hence which workgroup computes what) change with the batch size;
+    the arithmetic per output element does not, up to the order of the GroupNorm partial sums."""
+    import bench
+    model = bench.build_model(cuda, 1024)
+    g = torch.Generator().manual_seed(21)
+    imgs = (torch.rand(3, 3, 1024, 1024, generator=g) * 2 - 1).to(BF).to(cuda)
+    eps = torch.randn(3, 4, 128, 128, generator=g).to(BF).to(cuda)
+    out3 = bench.one_step(model, imgs, eps, 1)
+    out1 = bench.one_step(model, imgs[1:2].contiguous(), eps[1:2].contiguous(), 1)
+    assert out3.shape == (3, 3, 1024, 1024) and torch.isfinite(out3.float()).all()
+    a, b = out3[1:2].float(), out1.float()
+    mse = float(((a - b) ** 2).mean())
+    psnr = 10 * torch.log10(torch.tensor(4.0 / max(mse, 1e-20)))
+    assert psnr > 55, float(psnr)
+    # and differs from its neighbours (no cross-talk that would make every image alike)
+    assert float(((out3[0].float() - out3[1].float()) ** 2).mean()) > 100 * mse
