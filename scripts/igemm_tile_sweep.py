@@ -8,7 +8,7 @@ from lbm_amd import ops, _C
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-tiles = [-1, 0, 1, 3, 7, 8, 10, 11, 12, 13, 14]
+tiles = [int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else [-1, 0, 1, 3, 7, 8, 10, 11, 12, 13, 14]
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, res)
 images = (torch.rand(B, 3, res, res) * 2 - 1).to(torch.bfloat16).to(dev)
