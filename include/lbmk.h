@@ -80,6 +80,11 @@ int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
 int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int gn_groups);
 /* number of tile configurations; cfg i has block tile bm[i] x bn[i] */
 int lbmk_igemm_tiles(int* bm, int* bn, int cap);
+/* Diagnostics (no reference counterpart): tile ids 115 / 116 run the 512x128 / 256x256 tiles with in-kernel time
+ * stamps; this copies out 8 x uint64 per workgroup (100 MHz wall-clock stamps at start, after set-up, first stage
+ * landed, K loop done, epilogue issued, stores drained; shader-clock counter at the K loop's start and end).
+ * Synchronises the device.  Returns the hipError_t of the copy. */
+int lbmk_debug_igemm_times(unsigned long long* host, int nblocks);
 
 /* ------------------------------------------------------------------------
  * GroupNorm(+SiLU) over NHWC bf16.  Replaces torch.nn.GroupNorm(32, C, eps)
