@@ -240,6 +240,13 @@ int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, int OH, int O
 int lbmk_pack_conv_weight(const void* w, void* out, int N, int Cin, int KH, int KW, int n_p, int Kp,
                           int k_order, int swap_flip, void* stream);
 
+/* Weight-gradient GEMM on untransposed operands (dW = dY^T X of torch autograd's linear backward in the reference's
+ * training step): out[n][k] = sum_m a[m][n] * b[m][k], a bf16 [M][lda] (N columns), b bf16 [M][ldb] (K columns).
+ * splits > 1 cuts the m range; the kernel then writes f32 partials out[split][N][ldo] for lbmk_sum_partials
+ * (out_f32 must be 1).  splits == 1: out is the result, bf16 or f32, [N][ldo].  N, K multiples of 8. */
+int lbmk_gemm_tn(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
+                 int splits, int out_f32, void* stream);
+
 /* out[i] = sum_s partial[s][i]: the split-K partial products of a weight-gradient GEMM (f32 [nseg][n],
  * summed in a fixed order) -> bf16 (out_dtype 0) or f32 (1).  Part of the dW = dY^T X path above. */
 int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream);

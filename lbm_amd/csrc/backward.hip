@@ -242,10 +242,34 @@ extern "C" int lbmk_col2im(const void* dcol, void* dx, int B, int IH, int IW, in
   return lbmk_check_launch("col2im");
 }
 
+namespace {
+// few segments, many elements (split-K partials of a weight gradient): one thread per 4 consecutive elements,
+// segments added in order
+__global__ __launch_bounds__(256) void sum_partials_vec_kernel(const float* __restrict__ partial, void* __restrict__ out,
+                                                               int64_t n4, int64_t n, int nseg, int out_dtype) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 a = *(const f32x4*)(partial + i * 4);
+  for (int s = 1; s < nseg; ++s) a += *(const f32x4*)(partial + (int64_t)s * n + i * 4);
+  if (out_dtype) *(f32x4*)((float*)out + i * 4) = a;
+  else {
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = f2bf(a[e]);
+    *(u16x4*)((bf16_t*)out + i * 4) = o;
+  }
+}
+}  // namespace
+
 extern "C" int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream) {
   LBMK_REQUIRE(partial && out && n > 0 && nseg > 0, "sum_partials: n=%lld nseg=%d", (long long)n, nseg);
   LBMK_REQUIRE(out_dtype == 0 || out_dtype == 1, "sum_partials: out_dtype %d", out_dtype);
   LBMK_REQUIRE((n + 31) / 32 < (1LL << 31), "sum_partials: grid");
+  if (nseg <= 16 && n % 4 == 0 && n >= 4096 && lbmk_aligned(partial, 16) && lbmk_aligned(out, out_dtype ? 16 : 8)) {
+    hipLaunchKernelGGL(sum_partials_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                       out, n / 4, n, nseg, out_dtype);
+    return lbmk_check_launch("sum_partials");
+  }
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial, out, n,
                      nseg, out_dtype);
   return lbmk_check_launch("sum_partials");

@@ -644,12 +644,39 @@ def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torc
     return out
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[n][k] = sum_m a[m][n] * b[m][k]  (weight gradient: a = dY [M, N], b = X or col(X) given
-    row-major [M, K], or already transposed via ``b_t`` = [K, M]).  The reduction runs over the rows, so
-    both operands are transposed first and the row range is split across workgroups (split-K).
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None,
+            splits: Optional[int] = None) -> torch.Tensor:
+    """out[n][k] = sum_m a[m][n] * b[m][k]  (weight gradient: a = dY [M, N], b = X [M, K], both row-major).
+    The kernel reads both operands as they are (transposing LDS reads) and splits the row range across
+    workgroups; partial products are summed in a fixed order.
     ``out``: contiguous [N, K] destination (e.g. the parameter's slot in a flat gradient buffer)."""
-    return gemm_tn_t(transpose(_pad_rows8(a)), transpose(_pad_rows8(b)), out_dtype, out=out)
+    _need_gpu(a, b)
+    M, N = a.shape
+    K = b.shape[1]
+    if not (a.dtype == bf16 and b.dtype == bf16 and a.stride(1) == 1 and b.stride(1) == 1 and b.shape[0] == M
+            and N % 8 == 0 and K % 8 == 0 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        return gemm_tn_t(transpose(_pad_rows8(a)), transpose(_pad_rows8(b)), out_dtype, out=out)
+    if out is not None and (tuple(out.shape) != (N, K) or not out.is_contiguous() or out.dtype not in (bf16, torch.float32)):
+        out.copy_(gemm_tn(a, b, torch.float32, splits=splits)[:out.shape[0], :out.shape[1]])
+        return out
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    if splits is None:
+        # measured: a full grid of output tiles (>= one per CU) wants no split; below that ~400 workgroups in total,
+        # each with at least 512 rows of the reduction
+        splits = 1 if tiles >= 256 else max(1, min(-(-400 // tiles), M // 512))
+    chunk = -(-(-(-M // splits)) // 64) * 64
+    splits = -(-M // chunk)                        # no empty split after rounding the chunk to whole stages
+    if out is None:
+        out = torch.empty(N, K, dtype=out_dtype, device=a.device)
+    if splits == 1:
+        check(lib.lbmk_gemm_tn(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), K, 1,
+                               1 if out.dtype == torch.float32 else 0, _stream()), "lbmk_gemm_tn")
+        return out
+    part = torch.empty(splits, N, K, dtype=torch.float32, device=a.device)
+    check(lib.lbmk_gemm_tn(a.data_ptr(), b.data_ptr(), part.data_ptr(), M, N, K, a.stride(0), b.stride(0), K, splits, 1,
+                           _stream()), "lbmk_gemm_tn")
+    return sum_partials(part, out=out)
 
 
 def _pad_rows8(x: torch.Tensor) -> torch.Tensor:

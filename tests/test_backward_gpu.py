@@ -564,3 +564,22 @@ def test_unet_sd15_style_gradients(cuda, mode):
     assert (num / den) ** 0.5 < 6e-2
     if ctx_g is not None:
         assert ctx_g.grad is not None and rel_l2(ctx_g.grad, ctx_r.grad) < 6e-2
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(1000, 320, 200, None), (2048, 1280, 640, 1), (2048, 1280, 640, 3), (4096, 136, 72, None),
+                                          (64, 128, 128, None), (8192, 640, 2560, None), (333 * 8, 24, 1288, 4)])
+def test_gemm_tn_untransposed_operands(cuda, gen, M, N, K, splits):
+    """dW = dY^T X straight from the row-major operands (transposing LDS reads): ragged tiles in N and K, row counts
+    that are not whole stages, forced split counts, strided operands, bf16 output into a preallocated slot"""
+    from lbm_amd import ops
+    a = randbf(gen, M, N + 8)[:, :N]            # row stride N + 8
+    b = randbf(gen, M, K)
+    ref = a.float().t() @ b.float()
+    ag, bg = a.to(cuda), b.to(cuda)
+    ag = torch.empty(M, N + 8, dtype=BF, device=cuda)[:, :N].copy_(ag)
+    out = ops.gemm_tn(ag, bg, splits=splits)
+    assert out.dtype == torch.float32 and rel_l2(out, ref) < 2e-3
+    slot = torch.zeros(N * K + 16, dtype=BF, device=cuda)[8:8 + N * K].view(N, K)
+    ops.gemm_tn(ag, bg, out=slot, splits=splits)
+    assert rel_l2(slot, ref) < 4e-3
+    assert torch.equal(ops.gemm_tn(ag, bg, splits=splits), out)             # fixed summation order
