@@ -20,6 +20,14 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(-1, t.shape[-1])
 
 
+def _cast_pair(dg, db, dt):
+    """(dg, db) are rows 0 / 1 of one f32 [2, C] tensor: one conversion kernel for both"""
+    if dt == torch.float32:
+        return dg, db
+    both = dg._base.to(dt) if dg._base is not None and dg._base is db._base else None
+    return (both[0], both[1]) if both is not None else (dg.to(dt), db.to(dt))
+
+
 def _grad_sink(param):
     """The trainer's flat-gradient sink of ``param`` when one is accepting direct writes, else None.
     With a sink, a weight gradient is computed straight into the parameter's slot of the flat gradient
@@ -56,7 +64,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw = ops.gemm_tn(dy2, xc, out_dtype=weight.dtype)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)[0].to(weight.dtype)
+            db = ops.colsum(dy2, out_dtype=weight.dtype)[0]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         if ctx.has_rv and ctx.needs_input_grad[4]:
@@ -109,7 +117,7 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw = dwv.reshape(N, Cin, KH, KW).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2)[0, :N].to(weight.dtype)
+            db = ops.colsum(dy2, out_dtype=weight.dtype)[0, :N]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         if ctx.has_rv and ctx.needs_input_grad[4]:
@@ -133,7 +141,7 @@ class GroupNormFn(torch.autograd.Function):
         x, stats, g32, b32 = ctx.saved_tensors
         groups, silu, wdt = ctx.cfg
         dx, dg, db = ops.groupnorm_bwd(x, dy.contiguous(), stats, g32, b32, groups, silu)
-        return dx, dg.to(wdt), db.to(wdt), None, None, None
+        return (dx, *_cast_pair(dg, db, wdt), None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -150,7 +158,7 @@ class LayerNormFn(torch.autograd.Function):
         x, g32 = ctx.saved_tensors
         eps, wdt = ctx.cfg
         dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), g32, eps)
-        return dx, dg.to(wdt), db.to(wdt), None
+        return (dx, *_cast_pair(dg, db, wdt), None)
 
 
 class SiluFn(torch.autograd.Function):

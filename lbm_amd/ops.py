@@ -774,8 +774,8 @@ def groupnorm_bwd(x, dy, stats, gamma, beta, groups: int, silu: bool):
         raise _C.LbmkError(f"groupnorm_bwd: unsupported shape B={B} HW={HW} C={Cc} G={groups}")
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
-    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dgb = torch.empty(2, Cc, dtype=torch.float32, device=x.device)     # rows of one tensor: one cast converts both
+    dg, db = dgb[0], dgb[1]
     check(lib.lbmk_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), stats.data_ptr(), _ptr(gamma), _ptr(beta),
                                  dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), B, HW, Cc, groups, 1 if silu else 0,
                                  _stream()), "lbmk_groupnorm_bwd")
