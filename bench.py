@@ -102,8 +102,8 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--nfe", type=int, default=1)
@@ -126,6 +126,9 @@ def main():
     L = args.res // 8
     enc_eps = torch.randn(args.batch, 4, L, L, generator=torch.Generator().manual_seed(4321 + rank)).to(BF).to(device)
 
+    # set-up, not a benchmark step: the first pass packs every layer's weights into the kernels' layout and grows
+    # torch's caching allocator to the working set (reported as "setup_passes")
+    out = one_step(model, images, enc_eps, args.nfe)
     for _ in range(args.warmup):
         out = one_step(model, images, enc_eps, args.nfe)
     torch.cuda.synchronize()
@@ -162,7 +165,7 @@ def main():
         total_images = args.batch * world * args.steps
         line = {
             "metric": f"images/sec ({args.res}^2, {args.nfe}-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
-            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": 1,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "ms_per_image": round(elapsed / total_images * 1e3 * world, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (uniform [-1,1] images, seeded random-init weights of the reference architecture)",
