@@ -99,7 +99,33 @@ def _reducer_worker(rank, world, port, q):
         for p, o, q2 in zip(grp.params, grp.offsets, g2[::-1]):
             if q2 is not None:
                 ref[o:o + p.numel()] += q2.grad.reshape(-1) / world
-    q.put((rank, len(grp.buckets), float((flat_mean - ref).abs().max()), bool(all(p.data_ptr() >= grp.flat.data_ptr() for p in grp.params))))
+    # second step: two of the weights take the direct route the HIP autograd Functions use (the gradient is computed
+    # straight into the flat buffer through the parameter's sink and autograd gets None for it); the rest accumulate
+    # through autograd hooks.  Same buckets, same result.
+    class DirectLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            sink = getattr(w, "_lbmk_grad_sink", None)
+            assert sink is not None and sink.active
+            sink.write([w], lambda out: out.copy_(dy.t() @ x))
+            return dy @ w, None, dy.sum(0)
+
+    red.begin_step()
+    h = torch.relu(DirectLinear.apply(x, net[0].weight, net[0].bias))
+    h = DirectLinear.apply(h, net[2].weight, net[2].bias)
+    net[3](h).pow(2).sum().backward()
+    n_direct = len(red.written)
+    scale = red.finish()
+    err_direct = float((grp.grad * scale - ref).abs().max())
+    assert not red.active
+    q.put((rank, len(grp.buckets), float((flat_mean - ref).abs().max()), bool(all(p.data_ptr() >= grp.flat.data_ptr() for p in grp.params)),
+           n_direct, err_direct))
     dist.destroy_process_group()
 
 
@@ -117,7 +143,8 @@ def test_bucketed_gradient_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, nbuckets, err, views in res:
+    for rank, nbuckets, err, views, n_direct, err_direct in res:
         assert nbuckets >= 3
         assert err < 1e-5
         assert views
+        assert n_direct == 2 and err_direct < 1e-5
