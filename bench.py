@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 BF = torch.bfloat16
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 matrix peak
+HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E
 
 
 def build_model(device, res):
@@ -144,7 +145,7 @@ def main():
     assert out.shape == (args.batch, 3, args.res, args.res) and bool(torch.isfinite(out.float()).all())
     elapsed = D.max_over_ranks(elapsed, dist, device)
 
-    roofline, cpu = None, None
+    roofline, cpu, secondary = None, None, None
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the implicit-GEMM conv / linear kernel: every launch of one extra, untimed
         # step is bracketed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch
@@ -158,6 +159,18 @@ def main():
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
                     "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3)}
+        # the other kernels of the step, same event-bracketed measurement: the attention kernel against the MFMA
+        # peak, the normalisation / softmax passes against HBM (algorithmic bytes: 2 B read + 2 B written per element,
+        # plus 2 B for a separate statistics read; softmax 4 B read + 2 B written)
+        secondary = []
+        step_ms = elapsed / args.steps * 1e3
+        for kind, (ms, work, n) in sorted(prof["aux"].items()):
+            if kind == "flash_attn":
+                ach, peak, unit, bound = work / (ms * 1e-3) / 1e12, MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+            secondary.append({"kernel": kind, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                              "frac": round(ach / peak, 4), "launches": n, "share_of_step_time": round(ms / step_ms, 3)})
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model, min(16, os.cpu_count() or 1))
 
@@ -172,7 +185,7 @@ def main():
             "config": {"workload": f"LBM inference {args.res}x{args.res}, {args.nfe}-NFE, SDXL-style UNet (2.43B) + SD VAE encode/decode, "
                                    f"batch {args.batch}/GPU, data-parallel x{world}", "global_batch": args.batch * world,
                        "flops_per_image_T": 23.25 if (args.res, args.nfe) == (1024, 1) else None},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "secondary_kernels": secondary, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

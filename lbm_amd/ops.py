@@ -163,7 +163,28 @@ def igemm_profile_end() -> dict:
     p, _profile = _profile, None
     torch.cuda.synchronize()
     ms = sum(a.elapsed_time(b) for a, b in p["events"])
-    return {"ms": ms, "flops": p["flops"], "launches": len(p["events"])}
+    return {"ms": ms, "flops": p["flops"], "launches": len(p["events"]), "aux": aux_profile_summary(p)}
+
+
+def _timed(kind: str, work: float, launch):
+    """Run ``launch()``; while a profile is open, bracket it with HIP events on the launch stream and book
+    ``work`` (algorithmic bytes or FLOPs) under ``kind`` (the secondary kernels of bench.py's report)."""
+    if _profile is None:
+        return launch()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = launch()
+    b.record()
+    _profile.setdefault("aux", {}).setdefault(kind, []).append((a, b, work))
+    return r
+
+
+def aux_profile_summary(p: dict) -> dict:
+    """kind -> (ms, work, launches) of the secondary kernels recorded between igemm_profile_begin / _end."""
+    out = {}
+    for kind, recs in p.get("aux", {}).items():
+        out[kind] = (sum(a.elapsed_time(b) for a, b, _ in recs), sum(w for _, _, w in recs), len(recs))
+    return out
 
 
 def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None):
@@ -360,9 +381,10 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
         pbuf, _, nslab = fused
         stats = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
-        check(lib.lbmk_groupnorm_from_partials(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), pbuf.data_ptr(),
-                                               nslab, stats.data_ptr(), B, HW, Cc, groups, eps, 1 if silu else 0,
-                                               _stream()), "lbmk_groupnorm_from_partials")
+        _timed("groupnorm", 4.0 * x.numel(), lambda: check(
+            lib.lbmk_groupnorm_from_partials(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), pbuf.data_ptr(),
+                                             nslab, stats.data_ptr(), B, HW, Cc, groups, eps, 1 if silu else 0,
+                                             _stream()), "lbmk_groupnorm_from_partials"))
         return y
     nfl = lib.lbmk_groupnorm_scratch_floats(B, HW, Cc, groups)
     if nfl < 0:
@@ -373,8 +395,9 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
         buf = torch.empty(max(nfl, 1 << 16), dtype=torch.float32, device=x.device)
         _gn_scratch[key] = buf
     y = torch.empty_like(x)
-    check(lib.lbmk_groupnorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), buf.data_ptr(),
-                             B, HW, Cc, groups, eps, 1 if silu else 0, _stream()), "lbmk_groupnorm")
+    _timed("groupnorm", 6.0 * x.numel(), lambda: check(
+        lib.lbmk_groupnorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), buf.data_ptr(),
+                           B, HW, Cc, groups, eps, 1 if silu else 0, _stream()), "lbmk_groupnorm"))
     return y
 
 
@@ -385,8 +408,8 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty_like(x)
-    check(lib.lbmk_layernorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()),
-          "lbmk_layernorm")
+    _timed("layernorm", 4.0 * x.numel(), lambda: check(
+        lib.lbmk_layernorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()), "lbmk_layernorm"))
     return y
 
 
@@ -406,11 +429,11 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, h
         scale = 1.0 / math.sqrt(head_dim)
     o = torch.empty(B, Nq, heads * head_dim, dtype=bf16, device=q.device)
     lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device) if return_lse else None
-    check(lib.lbmk_flash_attn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, heads, Nq, Nk,
-                                  head_dim, q.stride(1), k.stride(1), vt.stride(1), o.stride(1),
-                                  q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale,
-                                  lse.data_ptr() if return_lse else None, _stream()),
-          "lbmk_flash_attn_fwd")
+    _timed("flash_attn", 4.0 * B * heads * Nq * Nk * head_dim, lambda: check(
+        lib.lbmk_flash_attn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), B, heads, Nq, Nk,
+                                head_dim, q.stride(1), k.stride(1), vt.stride(1), o.stride(1),
+                                q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale,
+                                lse.data_ptr() if return_lse else None, _stream()), "lbmk_flash_attn_fwd"))
     return (o, lse) if return_lse else o
 
 
@@ -464,7 +487,8 @@ def softmax_rows(s: torch.Tensor) -> torch.Tensor:
     cols = s.shape[-1]
     rows = s.numel() // cols
     p = torch.empty(s.shape, dtype=bf16, device=s.device)
-    check(lib.lbmk_softmax_rows(s.data_ptr(), p.data_ptr(), rows, cols, cols, cols, _stream()), "lbmk_softmax_rows")
+    _timed("softmax_rows", 6.0 * s.numel(), lambda: check(
+        lib.lbmk_softmax_rows(s.data_ptr(), p.data_ptr(), rows, cols, cols, cols, _stream()), "lbmk_softmax_rows"))
     return p
 
 
