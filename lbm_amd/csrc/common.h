@@ -8,6 +8,7 @@ typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 struct __attribute__((aligned(16))) u16x8 { bf16_t v[8]; };
 struct __attribute__((aligned(8))) u16x4 { bf16_t v[4]; };

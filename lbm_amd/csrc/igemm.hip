@@ -14,6 +14,7 @@
 // B operand of v_mfma_f32_16x16x32_bf16, so each lane ends up with 4 consecutive output
 // channels of one pixel (8-byte bf16 stores along the NHWC channel axis).
 #include "common.h"
+#include <stdlib.h>
 
 // Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116) record six 100 MHz
 // wall-clock stamps per workgroup: start, after set-up, first stage landed, K loop done, epilogue
@@ -189,7 +190,12 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // FAST: Cin % 64 == 0 -- every lane of a K-tile is on the same filter tap, so the
 // tap / channel walk is scalar and a load costs three vector ALU instructions.
 // OCC: workgroups meant to share a CU (caps the register budget at 512 / (OCC * waves per SIMD)).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false>
+// ROWA (3x3, stride 1, 'same' padding, Cin % 64 == 0): the K loop is bound by the bytes moved L2 -> LDS, and
+// the three taps of one filter row read the SAME input pixels shifted by one.  So the activation tile of a
+// (filter row, 64-channel chunk) pair is staged once as BM + 8 consecutive pixels of the flattened NHWC input and
+// the taps kw = 0, 1, 2 read it at row offsets 0, 1, 2: a third of the activation traffic.  Taps that fall outside
+// the image are zeroed on the fragment after the LDS read (per-lane 9-bit masks; waves without such pixels skip it).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false, bool ROWA = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 3) / 4) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   constexpr int STAGE = (BM + BN) * 128;        // bytes of one K-tile (64 deep) of both operands
   static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % RPP == 0, "tile shape");
   // all LDS in ONE array: a second __shared__ object makes hipcc drain vmcnt before every ds_read
-  __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * STAGE];
+  constexpr int ABYTES = (BM + 8) * 128;        // ROWA: one activation ring slot (BM + 8 pixels x 64 channels)
+  __shared__ __attribute__((aligned(16))) char smem[ROWA ? 2 * ABYTES + 2 * BN * 128 : (DBUF ? 2 : 1) * STAGE];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -311,6 +318,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   };
   tile_setup();
 
+  // ---- ROWA state --------------------------------------------------------------------------
+  // LDS row r of a slot holds flattened input pixel m0 + (kh - 1) * IW - 1 + r, so tap kw of output row j is LDS
+  // row j + kw.  The 16-byte chunk q of row r sits in slot q ^ g[(r >> 1) & 7]; this g keeps ds_read_b128 free of
+  // bank conflicts for fragment rows shifted by 0, 1 and 2 (the plain (r >> 1) & 7 swizzle only for shift 0).
+  constexpr unsigned SWZ = 0x62654210u;
+  // edge: 4 bits per row group i of this lane's output pixel: 1 = first image row, 2 = last image row, 4 = first
+  // column, 8 = last column.  Tap (kh, kw) is outside the image iff the pixel has an edge bit of
+  // (kh == 0 ? 1 : kh == 2 ? 2 : 0) | (kw == 0 ? 4 : kw == 2 ? 8 : 0).
+  unsigned edge = 0;
+  unsigned ra_vo0 = 0, ra_step = 0;   // byte offset of this thread's first staged pixel, and of RPP pixels
+  unsigned wave_edge = 0;             // OR of the edge bits over the wave's lanes and row groups (wave-uniform)
+  unsigned gpack = 0;                 // swizzle g of this lane's fragment rows shifted by kw = 0, 1, 2 (4 bits each)
+  if constexpr (ROWA) {
+    const int gsw = (int)(SWZ >> (((rsub >> 1) & 7) * 4)) & 7;
+    const int kkA = (slot ^ gsw) * 8;
+    const int64_t first = (int64_t)m0 - p.IW - 1;
+    const int64_t base_pix = first < 0 ? 0 : first;
+    int64_t rem = ((int64_t)(p.M / ohw) * p.IH * p.IW - base_pix) * p.a_cs * 2;
+    rem = rem > 0x7fffffff ? 0x7fffffff : rem;
+    a_base = A + base_pix * p.a_cs;
+    a_bytes = (int)rem;
+    const int r0 = (int)(first - base_pix) + rsub;   // may be negative: the byte offset then wraps past the descriptor (zeros)
+    {
+      const int pr = (lane & 15) >> 1, odd = lane & 1;
+      gpack = ((SWZ >> (pr * 4)) & 7) | (((SWZ >> (((pr + odd) & 7) * 4)) & 7) << 4) | (((SWZ >> (((pr + 1) & 7) * 4)) & 7) << 8);
+    }
+    ra_vo0 = (unsigned)(r0 * p.a_cs * 2 + (p.a_coff + kkA) * 2);
+    ra_step = (unsigned)(RPP * p.a_cs * 2);
+    unsigned any = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WM + i * 16 + (lane & 15);
+      unsigned e = 0;     // rows past M are never stored
+      if (m < p.M) {
+        const int b = m / ohw, r2 = m - b * ohw;
+        const int oy = r2 / p.OW, ox = r2 - oy * p.OW;
+        e = (oy == 0 ? 1u : 0u) | (oy + 1 == p.OH ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox + 1 == p.OW ? 8u : 0u);
+      }
+      edge |= e << (4 * i);
+      any |= e;
+    }
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt)
+      if (__ballot((any >> bt) & 1) != 0ull) wave_edge |= 1u << bt;
+    wave_edge = __builtin_amdgcn_readfirstlane(wave_edge);
+  }
+
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -383,13 +437,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   // the ds_read of the NEXT step's B fragment and, during the first k-step, one share of the second
   // k-step's A fragments, so LDS latency is covered by the step's own MFMAs; only the first
   // MI + 1 reads after the barrier are exposed.
-  auto compute = [&](const char* buf) __attribute__((always_inline)) {
+  // pa / pb: this lane's first fragment row of the activation / weight tile; offA0 / offA1: swizzled byte offsets
+  // of the two 32-deep k-steps inside an activation row.  mbit != 0 (ROWA): zero the activation fragments of
+  // pixels that have one of the edge bits `mbit`, once per fragment, right before its first MFMA.
+  auto compute_at = [&](const char* pa, const char* pb, int offA0, int offA1, unsigned mbit) __attribute__((always_inline)) {
     const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
-    const char* pa = buf + rdA;
-    const char* pb = buf + rdB;
     bf16x8 fa[2][MI], fb[2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
+    for (int i = 0; i < MI; ++i) fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + offA0);
     fb[0] = *(const bf16x8*)(pb + off0);
 #pragma unroll
     for (int st = 0; st < 2 * NI; ++st) {
@@ -400,16 +455,87 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       }
       if (ks == 0) {
 #pragma unroll
-        for (int i = j; i < MI; i += NI) fa[1][i] = *(const bf16x8*)(pa + i * 16 * 128 + off1);
+        for (int i = j; i < MI; i += NI) fa[1][i] = *(const bf16x8*)(pa + i * 16 * 128 + offA1);
+      }
+      if constexpr (ROWA) {
+        if (j == 0 && mbit) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const unsigned keep = ((edge >> (4 * i)) & mbit) ? 0u : 0xffffffffu;
+            u32x4 v = __builtin_bit_cast(u32x4, fa[ks][i]);
+            v &= keep;
+            fa[ks][i] = __builtin_bit_cast(bf16x8, v);
+          }
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[st & 1], fa[ks][i], acc[i][j], 0, 0, 0);
     }
   };
+  auto compute = [&](const char* buf) __attribute__((always_inline)) {
+    compute_at(buf + rdA, buf + rdB, (lq ^ rd_swz) << 4, ((4 + lq) ^ rd_swz) << 4, 0u);
+  };
 
   const int nkt = (p.K + 63) >> 6;
-  if constexpr (DBUF) {
+  if constexpr (ROWA) {
+    // Macro-step g = (filter row kh, channel chunk): its activation slot serves the three K-steps kw = 0, 1, 2.
+    // Weights: two stage buffers, tile of step s + 1 loaded under the MFMAs of step s.  Activations: two slots, the
+    // pieces of macro-step g + 1 spread over the three steps of macro-step g (its slot was last read in macro-step
+    // g - 1).  One barrier per K-step, as in the double-buffered loop.
+    char* acur = smem;
+    char* anext = smem + ABYTES;
+    char* wcur = smem + 2 * ABYTES;
+    char* wnext = wcur + BN * 128;
+    auto stage_w = [&](int tp, int chb, char* buf) __attribute__((always_inline)) {
+      // column of (tap, chunk) in the packed weight rows: tap-major (k_order 0) or chunk-major (k_order 1)
+      const unsigned soff = (unsigned)(p.k_order ? (chb * 9 + tp * 64) : (tp * p.Cin + chb)) * 2u;
+#pragma unroll
+      for (int i = 0; i < BI; ++i)
+        if ((BN % RPP == 0) || wave * 8 + RPP * i < BN)
+          buffer_lds16(W, w_bytes, w_vo[i], soff, buf + (wave * 8 + RPP * i) * 128);
+    };
+    auto stage_a = [&](int piece, int kh, int chb, char* buf) __attribute__((always_inline)) {   // piece AI = the 8 extra rows
+      const unsigned soff = (unsigned)(kh * p.IW * p.a_cs + chb) * 2u;
+      if (piece < AI || wave == 0)   // the extra piece starts at row BM = RPP * AI
+        buffer_lds16(a_base, a_bytes, ra_vo0 + ra_step * (unsigned)piece + soff, 0, buf + (piece < AI ? (wave * 8 + RPP * piece) * 128 : BM * 128));
+    };
+    const int ng = 3 * (p.Cin >> 6);
+    int kh = 0, chb = 0;
+#pragma unroll
+    for (int pc = 0; pc <= AI; ++pc) stage_a(pc, 0, 0, acur);
+    stage_w(0, 0, wcur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int rowB = (wn * WN + lr) * 128;
+    for (int g = 0; g < ng; ++g) {
+      int nkh = kh, nchb = chb + 64;
+      if (nchb >= p.Cin) { nchb = 0; ++nkh; }
+      const bool has_next = g + 1 < ng;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        if (kw < 2) stage_w(kh * 3 + kw + 1, chb, wnext);
+        else if (has_next) stage_w(nkh * 3, nchb, wnext);
+        if (has_next) {
+#pragma unroll
+          for (int pc = kw; pc <= AI; pc += 3) stage_a(pc, nkh, nchb, anext);
+        }
+        // read offsets are recomputed every step from one register: hoisted out of the loop, the per-tap addresses
+        // of the three unrolled steps are spilled, and their scratch reloads wait on the LDS-DMA counter
+        unsigned gp = gpack;
+        asm volatile("" : "+v"(gp));
+        const int gsw = (int)(gp >> (4 * kw)) & 7;
+        const unsigned sel = (kh == 0 ? 1u : kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : kw == 2 ? 8u : 0u);
+        compute_at(acur + rdA + kw * 128, wcur + rowB, (lq ^ gsw) << 4, ((4 + lq) ^ gsw) << 4, sel & wave_edge);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        char* tw = wcur; wcur = wnext; wnext = tw;
+      }
+      char* ta = acur; acur = anext; anext = ta;
+      kh = nkh;
+      chb = nchb;
+    }
+  } else if constexpr (DBUF) {
     // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
     // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
     // wave has finished when it passed the barrier that ended iteration kt-1.
@@ -452,21 +578,32 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {256, 160},    // 11: 16 waves (32x80 per wave): the UNet widths 320 ... 2560 are multiples of 160
                           {128, 64},     // 12: tile 1 double-buffered (small grids: few workgroups per CU to overlap with)
                           {64, 64},      // 13: tile 3 double-buffered
-                          {128, 128}};   // 14: tile 0 double-buffered
+                          {128, 128},    // 14: tile 0 double-buffered
+                          {384, 128}};   // 15: 12 waves (64x64 per wave), shared activation rows (ROWA): 3x3 stride-1 convolutions
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
+// LBMK_NO_ROWA=1 in the environment keeps the automatic choice on the per-tap tiles (same-box A/B runs)
+inline bool rowa_enabled() {
+  static const bool on = getenv("LBMK_NO_ROWA") == nullptr;
+  return on;
+}
+// shapes the shared-activation-row (ROWA) kernels take: 3x3, stride 1, one pixel of padding, same-size output
+inline bool rowa_ok(const lbmk_igemm_desc& d) {
+  return d.KH == 3 && d.KW == 3 && d.stride == 1 && !d.up2 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.IH && d.OW == d.IW &&
+         d.Cin % 64 == 0 && d.batch == 1;
+}
 
-template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1>
+template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1, bool ROWA = false>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
   if (d.gn_partial) {   // fused GroupNorm statistics: fast path only (checked by the caller)
     if constexpr (BM / WMs == 64 && BN / WNs == 64 && !STAMP)
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true>), grid, dim3(64 * WMs * WNs), 0, s, d);
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true, ROWA>), grid, dim3(64 * WMs * WNs), 0, s, d);
   } else if (fast_path(d))
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
-  else
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC, false, ROWA>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  else if constexpr (!ROWA)
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, false, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
@@ -535,6 +672,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   int tile = d.tile;
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
+    else if (rowa_enabled() && rowa_ok(d) && d.N >= 96 && d.N <= 256 && d.M >= 65536) tile = 15;   // measured 3-11 % ahead of tiles 7 / 8 / 10 on these
     else {
       // Cost model over the production tiles: time of the busiest CU.  A CU holding w workgroups of a
       // tile runs them `resident` at a time; a round of n co-resident workgroups costs a fixed part
@@ -570,7 +708,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
-  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14, "igemm: tile %d has no 64x64 wave strips", tile);
+  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14 || tile == 15, "igemm: tile %d has no 64x64 wave strips", tile);
+  if (tile == 15) LBMK_REQUIRE(rowa_ok(d), "igemm: tile %d takes 3x3 stride-1 same-size convolutions with Cin %% 64 == 0 only", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
     case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;
@@ -588,6 +727,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 12: launch<128, 64, 2, 2, true, false, 3>(d, s); break;
     case 13: launch<64, 64, 2, 2, true, false, 4>(d, s); break;
     case 14: launch<128, 128, 2, 2, true, false, 2>(d, s); break;
+    case 15: launch<384, 128, 6, 2, true, false, 1, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }

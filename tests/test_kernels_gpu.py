@@ -386,7 +386,48 @@ def test_conv3x3_many_tiles_two_images(ops, cuda, gen, tile):
     assert (y.float().cpu() - ref).abs().max() < 0.1
 
 
-@pytest.mark.parametrize("cout,tile", [(128, -1), (128, 8), (128, 10), (256, 7), (512, 7), (256, 0), (256, 14)])
+@pytest.mark.parametrize("tile", [15])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 23, 19, 128, 320), (2, 160, 161, 64, 320), (3, 9, 300, 64, 128),
+                                             (5, 8, 8, 192, 96), (1, 40, 1, 64, 64), (1, 1, 70, 64, 64)])
+def test_conv3x3_shared_activation_rows(ops, cuda, gen, tile, B, H, W, cin, cout):
+    """tiles that stage each (filter row, channel chunk) of the input once for its three taps: ragged M and N,
+    tiles straddling image rows and image boundaries, images narrower than a wave strip, one-pixel-wide / high images"""
+    x = randbf(gen, B, H, W, cin)
+    w = randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5)
+    b = randbf(gen, cout)
+    res = randbf(gen, B, H, W, cout)
+    pw = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
+    y = ops.conv2d(x.to(cuda), pw, residual=res.to(cuda), tile=tile)
+    ref = _conv_ref(x, w, b, 1, 1) + res.float()
+    assert rel_l2(y, ref) < 4e-3
+    assert (y.float().cpu() - ref).abs().max() < 0.1
+    y7 = ops.conv2d(x.to(cuda), pw, residual=res.to(cuda), tile=7)
+    assert (y.float() - y7.float()).abs().max() < 0.05     # same products, another summation order: one bf16 ulp
+
+
+@pytest.mark.parametrize("tile", [15])
+def test_conv3x3_shared_activation_rows_channel_window(ops, cuda, gen, tile):
+    """input read as a channel window of a wider tensor (concatenated skip connections)"""
+    B, H, W, cs, cin, cout = 2, 20, 24, 192, 64, 160
+    x = randbf(gen, B, H, W, cs)
+    w = randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5)
+    pw = ops.pack_conv_weight(w.to(cuda), None)
+    y = ops.conv2d(x.to(cuda), pw, cin_off=64, tile=tile)
+    ref = _conv_ref(x[..., 64:128].contiguous(), w, None, 1, 1)
+    assert rel_l2(y, ref) < 4e-3
+
+
+def test_conv3x3_shared_activation_rows_rejects_other_shapes(ops, cuda, gen):
+    from lbm_amd._C import LbmkError
+    x = randbf(gen, 1, 16, 16, 64).to(cuda)
+    pw = ops.pack_conv_weight(randbf(gen, 64, 64, 3, 3).to(cuda), None)
+    with pytest.raises(LbmkError):
+        ops.conv2d(x, pw, stride=2, tile=15)
+    with pytest.raises(LbmkError):
+        ops.conv2d(x, pw, up2=True, tile=15)
+
+
+@pytest.mark.parametrize("cout,tile", [(128, -1), (128, 8), (128, 10), (256, 7), (512, 7), (256, 0), (256, 14), (128, 15), (256, 15), (512, 15)])
 def test_conv_fused_groupnorm_stats(ops, cuda, gen, cout, tile):
     """the convolution's epilogue reduces the statistics of the GroupNorm that follows: same result as
     the stand-alone statistics pass, and equal to torch's group_norm on the stored tensor"""
