@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   // XCD-aware bijective remap: blocks that share an XCD (same blockIdx % 8) get
   // consecutive tiles, so the column tiles of one row panel hit the same L2.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = (int)gridDim.x;
+  // ROWA kernels are persistent: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the whole grid
+  const int nwg = ROWA ? ((p.M + BM - 1) / BM) * tiles_n : (int)gridDim.x;
   int m0, n0;
   auto tile_origin = [&](int orig) __attribute__((always_inline)) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   unsigned ra_vo0 = 0, ra_step = 0;   // byte offset of this thread's first staged pixel, and of RPP pixels
   unsigned wave_edge = 0;             // OR of the edge bits over the wave's lanes and row groups (wave-uniform)
   unsigned gpack = 0;                 // swizzle g of this lane's fragment rows shifted by kw = 0, 1, 2 (4 bits each)
-  if constexpr (ROWA) {
+  auto rowa_setup = [&]() __attribute__((always_inline)) {
     const int gsw = (int)(SWZ >> (((rsub >> 1) & 7) * 4)) & 7;
     const int kkA = (slot ^ gsw) * 8;
     const int64_t first = (int64_t)m0 - p.IW - 1;
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     ra_vo0 = (unsigned)(r0 * p.a_cs * 2 + (p.a_coff + kkA) * 2);
     ra_step = (unsigned)(RPP * p.a_cs * 2);
     unsigned any = 0;
+    edge = 0;
+    wave_edge = 0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + wm * WM + i * 16 + (lane & 15);
@@ -363,7 +366,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     for (int bt = 0; bt < 4; ++bt)
       if (__ballot((any >> bt) & 1) != 0ull) wave_edge |= 1u << bt;
     wave_edge = __builtin_amdgcn_readfirstlane(wave_edge);
-  }
+  };
+  if constexpr (ROWA) rowa_setup();
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -501,13 +505,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
         buffer_lds16(a_base, a_bytes, ra_vo0 + ra_step * (unsigned)piece + soff, 0, buf + (piece < AI ? (wave * 8 + RPP * piece) * 128 : BM * 128));
     };
     const int ng = 3 * (p.Cin >> 6);
-    int kh = 0, chb = 0;
+    const int rowB = (wn * WN + lr) * 128;
+    auto first_stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int pc = 0; pc <= AI; ++pc) stage_a(pc, 0, 0, acur);
-    stage_w(0, 0, wcur);
+      for (int pc = 0; pc <= AI; ++pc) stage_a(pc, 0, 0, acur);
+      stage_w(0, 0, wcur);
+    };
+    first_stage();
+    while (true) {
+    int kh = 0, chb = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int rowB = (wn * WN + lr) * 128;
     for (int g = 0; g < ng; ++g) {
       int nkh = kh, nchb = chb + 64;
       if (nchb >= p.Cin) { nchb = 0; ++nkh; }
@@ -535,6 +543,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       kh = nkh;
       chb = nchb;
     }
+    // Next tile of this workgroup: its staging state is set up and its first stage put in flight (into the two
+    // slots the last K-step did not read; every wave has passed that step's barrier) BEFORE this tile's epilogue,
+    // so the loads land under the output stores and no workgroup hand-over sits between two tiles.
+    const int em = m0 + wm * WM, en = n0 + wn * WN;
+    vblock += (int)gridDim.x;
+    const bool more = vblock < nwg;
+    if (more) {
+      tile_origin(vblock);
+      tile_setup();
+      rowa_setup();
+      first_stage();
+    }
+    igemm_epilogue<MI, NI, GNS>(p, acc, em, en, lane, zo, zr);
+    if (!more) break;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
   } else if constexpr (DBUF) {
     // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
     // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
@@ -588,6 +616,11 @@ inline bool rowa_enabled() {
   static const bool on = getenv("LBMK_NO_ROWA") == nullptr;
   return on;
 }
+// LBMK_NO_PERSIST=1: one workgroup per tile for the ROWA kernels as well (same-box A/B runs)
+inline bool persist_enabled() {
+  static const bool on = getenv("LBMK_NO_PERSIST") == nullptr;
+  return on;
+}
 // shapes the shared-activation-row (ROWA) kernels take: 3x3, stride 1, one pixel of padding, same-size output
 inline bool rowa_ok(const lbmk_igemm_desc& d) {
   return d.KH == 3 && d.KW == 3 && d.stride == 1 && !d.up2 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.IH && d.OW == d.IW &&
@@ -597,7 +630,9 @@ inline bool rowa_ok(const lbmk_igemm_desc& d) {
 template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1, bool ROWA = false>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
+  int nblocks = tm * tn;
+  if (ROWA && persist_enabled() && nblocks > lbmk_num_cus()) nblocks = lbmk_num_cus();   // one persistent workgroup per CU
+  dim3 grid((unsigned)nblocks, 1, (unsigned)d.batch);
   if (d.gn_partial) {   // fused GroupNorm statistics: fast path only (checked by the caller)
     if constexpr (BM / WMs == 64 && BN / WNs == 64 && !STAMP)
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true, ROWA>), grid, dim3(64 * WMs * WNs), 0, s, d);
