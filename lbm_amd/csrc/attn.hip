@@ -381,11 +381,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
-// Same softmax with the row held in registers (cols <= 1024 * NV): one read of the f32 scores instead of three.
-template <int NV>
-__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
-                                                               int cols, int64_t ld_in, int64_t ld_out) {
-  __shared__ float red[8];
+// Same softmax with the row held in registers (cols <= 4 * NT * NV): one read of the f32 scores instead of three.
+template <int NV, int NT = 256>
+__global__ __launch_bounds__(NT) void softmax_rows_reg_kernel(const float* __restrict__ S, bf16_t* __restrict__ P,
+                                                              int cols, int64_t ld_in, int64_t ld_out) {
+  constexpr int NWV = NT / 64;
+  __shared__ float red[2 * NWV];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* s = S + (int64_t)blockIdx.x * ld_in;
   bf16_t* p = P + (int64_t)blockIdx.x * ld_out;
@@ -394,14 +395,16 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = t + 256 * k;
+    const int i = t + NT * k;
     v[k] = i < nv ? *(const f32x4*)(s + 4 * i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
   float sum = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -409,12 +412,15 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
     for (int e = 0; e < 4; ++e) { v[k][e] = __expf(v[k][e] - mx); sum += v[k][e]; }
   }
   sum = wave_sum(sum);
-  if (lane == 0) red[4 + wave] = sum;
+  if (lane == 0) red[NWV + wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) tot += red[NWV + w];     // fixed order: run-to-run reproducible
+  const float inv = 1.0f / tot;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int i = t + 256 * k;
+    const int i = t + NT * k;
     if (i < nv) {
       u16x4 o;
 #pragma unroll
@@ -469,6 +475,9 @@ extern "C" int lbmk_softmax_rows(const float* s, void* p, int64_t rows, int cols
   if (cols <= 1024) SM_REG(1);
   else if (cols <= 4096) SM_REG(4);
   else if (cols <= 16384) SM_REG(16);
+  else if (cols <= 65536)    // 1024 threads x 16 float4: the 64k-token rows of the VAE attention at 2048^2
+    hipLaunchKernelGGL((softmax_rows_reg_kernel<16, 1024>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, s,
+                       (bf16_t*)p, cols, ld_in, ld_out);
   else
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
                        (bf16_t*)p, cols, ld_in, ld_out);

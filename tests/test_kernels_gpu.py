@@ -281,10 +281,14 @@ def test_flash_attn_strided_views(ops, cuda, gen):
     assert rel_l2(o, ref) < 6e-3
 
 
-def test_softmax_rows(ops, cuda, gen):
-    s = torch.randn(50, 1024, generator=gen) * 5
+@pytest.mark.parametrize("rows,cols", [(50, 1024), (7, 1000), (5, 4096), (3, 16384), (3, 20000), (2, 65536), (2, 70000)])
+def test_softmax_rows(ops, cuda, gen, rows, cols):
+    """every row-length class: register-resident rows (256 threads up to 16k columns, 1024 threads up to 64k) and the
+    three-pass kernel beyond"""
+    s = torch.randn(rows, cols, generator=gen) * 5
     p = ops.softmax_rows(s.to(cuda))
     assert rel_l2(p, torch.softmax(s, -1)) < 4e-3
+    assert (p.float().sum(-1).cpu() - 1).abs().max() < 2e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, BF])
