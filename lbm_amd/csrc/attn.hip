@@ -23,14 +23,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The softmax arithmetic, not the MFMA pipe, bounds this kernel (per score: scale-and-shift, exp2, sum,
 // bf16 pack, running max on the vector ALU against 16 MFMA cycles), so the loop keeps vector work
 // minimal: packed f32 math, LDS read offsets hoisted out of the loop, and the rescale of the output
-// accumulator only when some row's running maximum actually moved.  128 registers -> 4 waves per SIMD.
+// accumulator only when some row's running maximum actually moved.  136 registers -> 3 waves per SIMD (capped at
+// 128 the kernel spills 6 registers and measures 4-6 % slower).
 __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
     int64_t sk, int64_t svt, int64_t so, float scale_log2e, float* __restrict__ LSE) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KB * 128];
-  char* sK = smem;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
-  char* sV = smem + KB * 128;    // [d][64 keys]   same image
+  // two stage buffers of (K tile, V^T tile): the loads of tile i+1 are issued right after the barrier that
+  // publishes tile i and land under its MFMAs / softmax; one barrier per tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KB * 128];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -71,23 +72,33 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
   for (int c = 0; c < 8; ++c) voff[c] = r * 128 + 8 * h + ((c ^ rswz) << 4);
   const f32x2 sc2 = {scale_log2e, scale_log2e};
 
-  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
+  auto stage = [&](int kv0, char* buf) __attribute__((always_inline)) {
+    char* dK = buf;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
+    char* dV = buf + KB * 128;    // [d][64 keys]   same image
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = rsub + 32 * i;
       const int key = kv0 + row;
       const bf16_t* src = key < Nk ? K + (int64_t)key * ldk + cs * 8 : (const bf16_t*)attn_zero_page;
-      glds16(src, sK + (wave * 8 + 32 * i) * 128);
+      glds16(src, dK + (wave * 8 + 32 * i) * 128);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = rsub + 32 * i;   // channel d
       const int key = kv0 + cs * 8;
       const bf16_t* src = key < Nk ? Vt + (int64_t)row * ldvt + key : (const bf16_t*)attn_zero_page;
-      glds16(src, sV + (wave * 8 + 32 * i) * 128);
+      glds16(src, dV + (wave * 8 + 32 * i) * 128);
     }
+  };
+  stage(0, smem);
+  int cur = 0;
+  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();     // tile kv0 is in place, and every wave is done reading the other buffer (tile kv0 - KB)
+    const char* sK = smem + cur * (2 * KB * 128);
+    const char* sV = sK + KB * 128;
+    cur ^= 1;
+    if (kv0 + KB < Nk) stage(kv0 + KB, smem + cur * (2 * KB * 128));
 
     // ---- S^T = K Q^T : two 32-key sub-tiles -------------------------------------------
     f32x16 s[2];
@@ -163,7 +174,6 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
         }
     }
-    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
