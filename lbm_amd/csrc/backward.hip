@@ -313,7 +313,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float dsilu_f(float z) { const float s = sigmoid_f(z); return s * (1.f + z * (1.f - s)); }
 // d/dg gelu_erf(g) = Phi(g) + g * phi(g)
 __device__ __forceinline__ float dgelu_erf_f(float g) {
-  return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+  return 0.5f * (1.f + erf_as_f(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
 }
 
 // ---- GroupNorm(+SiLU) backward -------------------------------------------------------------------
