@@ -207,9 +207,8 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
   constexpr int KROW = KS * 32;          // bytes per key row of the K image
   constexpr int KCHUNKS = KB * KS * 2;   // 16-byte chunks of one K tile
   constexpr int KI = (KCHUNKS + 255) / 256;
-  __shared__ __attribute__((aligned(16))) char smem[KB * KROW + DT * 32 * 128];
-  char* sK = smem;
-  char* sV = smem + KB * KROW;
+  constexpr int STAGE = KB * KROW + DT * 32 * 128;   // one (K tile, V^T tile) pair
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];   // two stage buffers, as in the head_dim-64 kernel
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -247,7 +246,9 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
   const int cs = slot ^ ((rsub >> 1) & 7);
   const int rswz = (r >> 1) & 7;
 
-  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
+  auto stage = [&](int kv0, char* buf) __attribute__((always_inline)) {
+    char* dK = buf;
+    char* dV = buf + KB * KROW;
 #pragma unroll
     for (int i = 0; i < KI; ++i) {
       const int idx = i * 256 + t;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
         const int key = kv0 + row;
         const bf16_t* src = (key < Nk && c * 8 < DH) ? K + (int64_t)key * ldk + c * 8
                                                      : (const bf16_t*)attn_zero_page;
-        glds16(src, sK + (i * 256 + wave * 64) * 16);
+        glds16(src, dK + (i * 256 + wave * 64) * 16);
       }
     }
 #pragma unroll
@@ -265,10 +266,18 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
       const int key = kv0 + cs * 8;
       const bf16_t* src = (row < DH && key < Nk) ? Vt + (int64_t)row * ldvt + key
                                                  : (const bf16_t*)attn_zero_page;
-      glds16(src, sV + (wave * 8 + 32 * i) * 128);
+      glds16(src, dV + (wave * 8 + 32 * i) * 128);
     }
+  };
+  stage(0, smem);
+  int cur = 0;
+  for (int kv0 = 0; kv0 < Nk; kv0 += KB) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();     // tile kv0 is in place, and every wave is done reading the other buffer
+    const char* sK = smem + cur * STAGE;
+    const char* sV = sK + KB * KROW;
+    cur ^= 1;
+    if (kv0 + KB < Nk) stage(kv0 + KB, smem + cur * STAGE);
 
     f32x16 s[2];
 #pragma unroll
@@ -298,8 +307,15 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some row's maximum moved: rescale
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      m_run = m_new;
+    }
     float psum = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
@@ -310,11 +326,7 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
         psum += pv;
         pf[kt][e >> 3][e & 7] = (__bf16)pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    l_run += psum;
 
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -331,7 +343,6 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
         }
     }
-    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
