@@ -22,7 +22,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The softmax arithmetic, not the MFMA pipe, bounds this kernel (per score: scale-and-shift, exp2, sum,
 // bf16 pack, running max on the vector ALU against 16 MFMA cycles), so the loop keeps vector work
-// minimal: packed f32 math, LDS read offsets hoisted out of the loop, and the rescale of the output
+// minimal: scalar fma / add pairs (packed f32 instructions issue slower beside MFMAs: +2 % measured with the
+// file built -fno-slp-vectorize), LDS read offsets hoisted out of the loop, and the rescale of the output
 // accumulator only when some row's running maximum actually moved.  136 registers -> 3 waves per SIMD (capped at
 // 128 the kernel spills 6 registers and measures 4-6 % slower).
 __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
@@ -70,7 +71,6 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
   for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ rswz) << 4);
 #pragma unroll
   for (int c = 0; c < 8; ++c) voff[c] = r * 128 + 8 * h + ((c ^ rswz) << 4);
-  const f32x2 sc2 = {scale_log2e, scale_log2e};
 
   auto stage = [&](int kv0, char* buf) __attribute__((always_inline)) {
     char* dK = buf;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
@@ -143,21 +143,21 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
         }
       m_run = m_new;
     }
-    const f32x2 nm2 = {-m_run, -m_run};
-    f32x2 ps2 = {0.f, 0.f};
+    const float nm = -m_run;
+    float ps0 = 0.f, ps1 = 0.f;
     bf16x8 pf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
-        f32x2 v = {s[kt][e], s[kt][e + 1]};
-        v = v * sc2 + nm2;
-        const f32x2 pv = {__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)};
-        ps2 += pv;
-        pf[kt][e >> 3][e & 7] = (__bf16)pv.x;
-        pf[kt][e >> 3][(e & 7) + 1] = (__bf16)pv.y;
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], scale_log2e, nm));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e + 1], scale_log2e, nm));
+        ps0 += p0;
+        ps1 += p1;
+        pf[kt][e >> 3][e & 7] = (__bf16)p0;
+        pf[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
       }
-    l_run += ps2.x + ps2.y;
+    l_run += ps0 + ps1;
 
     // ---- O^T += V^T P^T ------------------------------------------------------------------
 #pragma unroll
