@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
   const int cs = slot ^ ((rsub >> 1) & 7);
   const int rswz = (r >> 1) & 7;
   // loop-invariant LDS read offsets of this lane's fragments
-  int koff[4], voff[8];
+  int koff[4], voff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) koff[ks] = r * 128 + (((2 * ks + h) ^ rswz) << 4);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) voff[c] = r * 128 + 8 * h + ((c ^ rswz) << 4);
+  for (int c = 0; c < 4; ++c) voff[c] = r * 128 + (((2 * c + h) ^ rswz) << 4);   // 8 keys 16 c + 8 h .. of V^T row r
 
   auto stage = [&](int kv0, char* buf) __attribute__((always_inline)) {
     char* dK = buf;               // [key][64 d]    128-byte rows, 16-byte slots XOR-swizzled
@@ -158,6 +158,19 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
         pf[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
       }
     l_run += ps0 + ps1;
+    // A lane pair (l, l + 32) holds the keys of a 16-key step interleaved in fours (l: 0-3 and 8-11, l + 32: 4-7 and
+    // 12-15).  Swapping the second packed half of l with the first of l + 32 gives each lane 8 CONSECUTIVE keys
+    // (l: 0-7, l + 32: 8-15), so its V^T fragment is one 16-byte LDS read instead of two 8-byte reads glued by moves.
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const u32x4 w = __builtin_bit_cast(u32x4, pf[kt][ss]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+        const u32x4 x = {s0[0], s1[0], s0[1], s1[1]};
+        pf[kt][ss] = __builtin_bit_cast(bf16x8, x);
+      }
 
     // ---- O^T += V^T P^T ------------------------------------------------------------------
 #pragma unroll
@@ -166,11 +179,7 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-          const int c1 = 4 * kt + 2 * ss;
-          const uint2 lo = *(const uint2*)(sV + dt * 32 * 128 + voff[c1]);
-          const uint2 hi = *(const uint2*)(sV + dt * 32 * 128 + voff[c1 + 1]);
-          const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, pk);
+          const bf16x8 vf = *(const bf16x8*)(sV + dt * 32 * 128 + voff[2 * kt + ss]);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
         }
     }
