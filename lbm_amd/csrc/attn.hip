@@ -24,8 +24,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // bf16 pack, running max on the vector ALU against 16 MFMA cycles), so the loop keeps vector work
 // minimal: scalar fma / add pairs (packed f32 instructions issue slower beside MFMAs: +2 % measured with the
 // file built -fno-slp-vectorize), LDS read offsets hoisted out of the loop, and the rescale of the output
-// accumulator only when some row's running maximum actually moved.  136 registers -> 3 waves per SIMD (capped at
-// 128 the kernel spills 6 registers and measures 4-6 % slower).
+// accumulator only when some row's running maximum actually moved.  116 registers; 3 and 4 waves per SIMD measure
+// the same.
 __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
@@ -336,19 +336,26 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
         pf[kt][e >> 3][e & 7] = (__bf16)pv;
       }
     l_run += psum;
+    // lane pair exchange: 8 consecutive keys per lane and 16-key step (see the head_dim-64 kernel)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const u32x4 w = __builtin_bit_cast(u32x4, pf[kt][ss]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+        const u32x4 x = {s0[0], s1[0], s0[1], s1[1]};
+        pf[kt][ss] = __builtin_bit_cast(bf16x8, x);
+      }
 
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      const char* vrow = sV + (32 * dt + r) * 128 + 8 * h;
+      const char* vrow = sV + (32 * dt + r) * 128;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-          const int c1 = 4 * kt + 2 * ss;
-          const uint2 lo = *(const uint2*)(vrow + ((c1 ^ rswz) << 4));
-          const uint2 hi = *(const uint2*)(vrow + (((c1 + 1) ^ rswz) << 4));
-          const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, pk);
+          const bf16x8 vf = *(const bf16x8*)(vrow + (((4 * kt + 2 * ss + h) ^ rswz) << 4));
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o[dt], 0, 0, 0);
         }
     }
