@@ -607,7 +607,8 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {128, 64},     // 12: tile 1 double-buffered (small grids: few workgroups per CU to overlap with)
                           {64, 64},      // 13: tile 3 double-buffered
                           {128, 128},    // 14: tile 0 double-buffered
-                          {384, 128}};   // 15: 12 waves (64x64 per wave), shared activation rows (ROWA): 3x3 stride-1 convolutions
+                          {384, 128},    // 15: 12 waves (64x64 per wave), shared activation rows (ROWA): 3x3 stride-1 convolutions
+                          {192, 128}};   // 16: 8 waves (48x64 per wave), double-buffered, two workgroups per CU (2 x 80 KB of LDS)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
@@ -721,7 +722,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
                                    {8, 512, 128, 1, true, 0.f, 13.7f, 1.14f, 1.20f},  {10, 256, 128, 2, false, 0.f, 8.3f, 0.87f, 0.38f},
                                    {0, 128, 128, 4, false, 2.8f, 4.8f, 0.55f, 0.34f}, {1, 128, 64, 4, false, 5.0f, 1.9f, 0.34f, 0.23f},
                                    {3, 64, 64, 8, false, 2.5f, 2.2f, 0.25f, 0.30f},   {12, 128, 64, 3, true, 1.9f, 4.5f, 0.34f, 0.55f},
-                                   {13, 64, 64, 4, true, 3.3f, 2.0f, 0.24f, 0.42f},   {14, 128, 128, 2, true, 0.f, 7.9f, 0.20f, 0.84f}};
+                                   {13, 64, 64, 4, true, 3.3f, 2.0f, 0.24f, 0.42f},   {14, 128, 128, 2, true, 0.f, 7.9f, 0.20f, 0.84f},
+                                   {16, 192, 128, 2, true, 0.f, 12.0f, 0.58f, 0.90f}};   // offered to batched launches only (below)
       const int cus = lbmk_num_cus();
       const int nkt = (d.K + 63) / 64;
       double best = 1e300;
@@ -729,6 +731,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       for (const Cand& c : cands) {
         if (gn && !(c.tile == 0 || c.tile == 7 || c.tile == 8 || c.tile == 10 || c.tile == 14)) continue;   // statistics strips are 64 rows x 64 columns per wave
         if (d.act == LBMK_ACT_GEGLU && c.tile == 11) continue;              // odd number of column groups per wave
+        if (c.tile == 16 && d.batch < 8) continue;   // measured ahead only on the per-image V^T projections (many small problems)
         const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
         long w = (blocks + cus - 1) / cus;
         const long full = w / c.resident;
@@ -763,6 +766,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 13: launch<64, 64, 2, 2, true, false, 4>(d, s); break;
     case 14: launch<128, 128, 2, 2, true, false, 2>(d, s); break;
     case 15: launch<384, 128, 6, 2, true, false, 1, true>(d, s); break;
+    case 16: launch<192, 128, 4, 2, true, false, 2>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }

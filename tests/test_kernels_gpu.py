@@ -43,7 +43,7 @@ def _conv_ref(x_nhwc, w, b, stride, padding, up2=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (128, 128, 64), (17, 320, 1280), (1000, 72, 320)])
 def test_linear(ops, cuda, gen, tile, M, N, K):
     x = randbf(gen, M, K)
@@ -88,7 +88,7 @@ def test_geglu(ops, cuda, gen):
     w = randbf(gen, 2 * Fh, K, scale=K ** -0.5)
     b = randbf(gen, 2 * Fh)
     pw = ops.pack_geglu_weight(w.to(cuda), b.to(cuda))
-    for tile in (-1, 0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14):
+    for tile in (-1, 0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 16):
         y = ops.linear(x.to(cuda), pw, tile=tile)
         h = x.float() @ w.float().t() + b.float()
         ref = h[:, :Fh] * F.gelu(h[:, Fh:])
@@ -359,7 +359,7 @@ def test_errors_are_loud(ops, cuda, gen):
         ops.silu(torch.zeros(8, dtype=BF))  # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("tile", [5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 def test_conv3x3_wide_tiles(ops, cuda, gen, tile):
     """double-buffered 8-wave tiles (256x256 / 256x128) on a convolution with ragged M and N"""
     B, H, W, cin, cout = 2, 23, 19, 128, 320
@@ -375,7 +375,7 @@ def test_conv3x3_wide_tiles(ops, cuda, gen, tile):
     assert rel_l2(y2, _conv_ref(x, w, b, 1, 1, up2=True)) < 4e-3
 
 
-@pytest.mark.parametrize("tile", [7, 8, 11])
+@pytest.mark.parametrize("tile", [7, 8, 11, 16])
 def test_conv3x3_many_tiles_two_images(ops, cuda, gen, tile):
     """16-wave tiles on a grid larger than the CU count, output tiles straddling the image boundary"""
     B, H, W, cin, cout = 2, 160, 161, 64, 320
