@@ -84,3 +84,20 @@ def test_get_model_loads_checkpoint_dir(tmp_path):
         with torch.device("meta"):
             with pytest.raises(RuntimeError, match="Missing key"):
                 get_model(str(tmp_path), device="meta")
+
+
+def test_shared_row_lds_swizzle_is_conflict_free_for_all_tap_shifts():
+    """the slot table of the shared-activation-row convolution tile (SWZ in igemm.hip) keeps the 16-lane groups of
+    ds_read_b128 conflict-free for fragment rows shifted by 0, 1 and 2; the plain (row >> 1) & 7 swizzle only for 0"""
+    import importlib.util, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_swizzle_search", os.path.join(root, "scripts", "lds_swizzle_search.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(root, "lbm_amd", "csrc", "igemm.hip")).read()
+    packed = int(re.search(r"constexpr unsigned SWZ = (0x[0-9a-fA-F]+)u;", src).group(1), 16)
+    h = [(packed >> (4 * (r >> 1))) & 7 for r in range(16)]
+    assert mod.conflict_free(h)
+    plain = [(r >> 1) & 7 for r in range(16)]
+    assert mod.conflict_free(plain, (0,)) and not mod.conflict_free(plain, (1,)) and not mod.conflict_free(plain, (2,))
+    assert mod.search() == h
