@@ -102,6 +102,16 @@ int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta
                    float* scratch, int B, int HW, int C, int G, float eps,
                    int silu, void* stream);
 
+/* lbmk_groupnorm for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arithmetic and kernels as
+ * lbmk_groupnorm; the slab partials and statistics live in a fixed device array inside the library
+ * (lbmk_groupnorm_static_max_floats() floats = 1 MiB per GPU, held until the process ends) instead of a caller
+ * workspace.  Shapes whose lbmk_groupnorm_scratch_floats() exceeds that return LBMK_ERR_ARG.  Calls no hipMalloc /
+ * hipFree.  All calls on one GPU share the array: calls that overlap on one GPU (different streams) race. */
+int64_t lbmk_groupnorm_static_max_floats(void);
+int lbmk_groupnorm_static(const void* x, void* y, const float* gamma, const float* beta,
+                          int B, int HW, int C, int G, float eps, int silu, void* stream);
+
 /* Same normalisation, with the statistics pass replaced by partial sums a producer already wrote
  * (lbmk_igemm with gn_partial): partial is [B][G][nslab][2] f32; scratch holds 2*B*G floats. */
 int lbmk_groupnorm_from_partials(const void* x, void* y, const float* gamma, const float* beta,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "lbmk_groupnorm_from_partials": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_groupnorm_scratch_floats": (i64, [i32, i32, i32, i32]),
     "lbmk_groupnorm": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "lbmk_groupnorm_static_max_floats": (i64, []),
+    "lbmk_groupnorm_static": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_layernorm": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
     "lbmk_flash_attn_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                   i64, i64, i64, i64, f32, vp, vp]),

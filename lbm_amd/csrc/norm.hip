@@ -6,6 +6,7 @@
 // slab partials into mean / rstd; (3) apply y = x*a[c] + b[c] (+SiLU) with the same mapping.
 // No float atomics anywhere (LDS included): every sum has a fixed order, results are bit-reproducible.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -245,15 +246,19 @@ extern "C" int64_t lbmk_groupnorm_scratch_floats(int B, int HW, int C, int G) {
   return (int64_t)B * G * pl.nslab * 2 + (int64_t)B * G * 2;
 }
 
-extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta,
-                              float* scratch, int B, int HW, int C, int G, float eps, int silu,
-                              void* stream) {
-  LBMK_REQUIRE(x && y && scratch, "groupnorm: null pointer");
-  LBMK_REQUIRE(B > 0 && HW > 0 && B <= 65535, "groupnorm: B=%d HW=%d", B, HW);
+// the three launches of a GroupNorm pass; scratch = [B*G*nslab*2 slab partials | B*G*2 statistics] floats
+static int gn_run(const char* what, const void* x, void* y, const float* gamma, const float* beta, float* scratch,
+                  int64_t scratch_cap, int B, int HW, int C, int G, float eps, int silu, void* stream) {
+  LBMK_REQUIRE(x && y && scratch, "%s: null pointer", what);
+  LBMK_REQUIRE(B > 0 && HW > 0 && B <= 65535, "%s: B=%d HW=%d", what, B, HW);
   GnPlan pl;
-  LBMK_REQUIRE(gn_plan(B, HW, C, G, &pl), "groupnorm: unsupported C=%d G=%d", C, G);
-  LBMK_REQUIRE(G / pl.S <= 32, "groupnorm: more than 32 groups per segment");
-  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16), "groupnorm: x / y must be 16-byte aligned");
+  LBMK_REQUIRE(gn_plan(B, HW, C, G, &pl), "%s: unsupported C=%d G=%d", what, C, G);
+  LBMK_REQUIRE(G / pl.S <= 32, "%s: more than 32 groups per segment", what);
+  LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(y, 16), "%s: x / y must be 16-byte aligned", what);
+  const int64_t need = (int64_t)B * G * pl.nslab * 2 + (int64_t)B * G * 2;
+  LBMK_REQUIRE(scratch_cap < 0 || need <= scratch_cap,
+               "%s: B=%d HW=%d C=%d G=%d needs %lld scratch floats, the built-in buffer holds %lld", what, B, HW, C, G,
+               (long long)need, (long long)scratch_cap);
   hipStream_t s = (hipStream_t)stream;
   float* partial = scratch;
   float* stats = scratch + (int64_t)B * G * pl.nslab * 2;
@@ -269,7 +274,56 @@ extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const 
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y,
                        stats, gamma, beta, HW, C, G, pl.nch, pl.rpp, pl.rows_per_slab);
-  return lbmk_check_launch("groupnorm");
+  return lbmk_check_launch(what);
+}
+
+extern "C" int lbmk_groupnorm(const void* x, void* y, const float* gamma, const float* beta,
+                              float* scratch, int B, int HW, int C, int G, float eps, int silu,
+                              void* stream) {
+  return gn_run("groupnorm", x, y, gamma, beta, scratch, -1, B, HW, C, G, eps, silu, stream);
+}
+
+// ---- GroupNorm for callers that cannot allocate: the slab partials and statistics live in a fixed device array ----
+// Every kernel of the pass writes each scratch word before any kernel reads it (slab partials by gn_stats_kernel,
+// statistics by gn_finalize_kernel), so nothing has to be cleared between calls.
+#define LBMK_GN_STATIC_FLOATS (1 << 18)     // 1 MiB per device, held until the process ends
+static __device__ __align__(256) float gn_static_scratch[LBMK_GN_STATIC_FLOATS];
+
+// Device address of gn_static_scratch on the current device.  The array's name is only a host-side handle, and each
+// GPU holds its own copy at its own address: resolved once per device, with that device current.
+static int gn_static_ptr(float** out) {
+  enum { MAX_DEV = 64 };
+  static float* ptrs[MAX_DEV];
+  static std::mutex mu;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    lbmk_set_error("groupnorm_static: hipGetDevice -> %d (%s)", dev, hipGetErrorString(e));
+    return LBMK_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[dev]) {
+    float* p = nullptr;
+    e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(gn_static_scratch));
+    if (e != hipSuccess || !p) {
+      lbmk_set_error("groupnorm_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return LBMK_ERR_LAUNCH;
+    }
+    ptrs[dev] = p;
+  }
+  *out = ptrs[dev];
+  return LBMK_OK;
+}
+
+extern "C" int64_t lbmk_groupnorm_static_max_floats(void) { return LBMK_GN_STATIC_FLOATS; }
+
+extern "C" int lbmk_groupnorm_static(const void* x, void* y, const float* gamma, const float* beta, int B, int HW,
+                                     int C, int G, float eps, int silu, void* stream) {
+  float* scratch = nullptr;
+  const int rc = gn_static_ptr(&scratch);
+  if (rc != LBMK_OK) return rc;
+  return gn_run("groupnorm_static", x, y, gamma, beta, scratch, LBMK_GN_STATIC_FLOATS, B, HW, C, G, eps, silu,
+                stream);
 }
 
 extern "C" int lbmk_groupnorm_from_partials(const void* x, void* y, const float* gamma, const float* beta,
