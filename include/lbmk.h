@@ -294,11 +294,13 @@ int lbmk_latent_loss_bwd(const void* pred, const void* z_src, const void* z, con
                          int z_dtype, void* stream);
 
 /* Pixel reconstruction loss, l2 / l1 variants (lbm_model.py:197-249): out[b] = mean over the sample of
- * ((clamp(dec, -1, 1) - target) * mask)^2 or |.|; the gradient flows through the clamp inside [-1, 1] only. */
+ * ((c(dec) - target) * mask)^2 or |.|.  clamp = 1: c clips to [-1, 1] and the gradient flows inside [-1, 1] only (the
+ * reference clamps the VAE-decoded prediction, lbm_model.py:233-234); clamp = 0: c is the identity (no VAE, :235-236). */
 int lbmk_pixel_loss(const void* dec, const void* target, const uint8_t* mask, float* out, int B,
-                    int64_t per_sample, int l1, int dec_dtype, int tgt_dtype, void* stream);
+                    int64_t per_sample, int l1, int clamp, int dec_dtype, int tgt_dtype, void* stream);
 int lbmk_pixel_loss_bwd(const void* dec, const void* target, const uint8_t* mask, const float* gout,
-                        void* ddec, int B, int64_t per_sample, int l1, int dec_dtype, int tgt_dtype, void* stream);
+                        void* ddec, int B, int64_t per_sample, int l1, int clamp, int dec_dtype, int tgt_dtype,
+                        void* stream);
 
 /* One AdamW step (torch.optim.AdamW semantics, the optimizer named by the reference's training configs,
  * src/lbm/trainer/trainer.py:118-121) over a flat range: p, g bf16 [n]; m, v f32 [n]; step counts from 1;

@@ -107,8 +107,8 @@ SIGNATURES = {
     "lbmk_geglu_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "lbmk_softmax_bwd_rows": (i32, [vp, vp, vp, i64, i32, f32, vp]),
     "lbmk_latent_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
-    "lbmk_pixel_loss": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
-    "lbmk_pixel_loss_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
+    "lbmk_pixel_loss": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
+    "lbmk_pixel_loss_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "lbmk_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 

@@ -402,19 +402,21 @@ class LatentLossFn(torch.autograd.Function):
 
 
 class PixelLossFn(torch.autograd.Function):
-    """per-sample mean of ((clamp(dec, -1, 1) - target) * mask)^2 or |.| (lbm_model.py:197-249, l2 / l1)."""
+    """per-sample mean of ((c(dec) - target) * mask)^2 or |.| (lbm_model.py:197-249, l2 / l1); c clips to [-1, 1]
+    when ``clamp`` (a VAE-decoded prediction, :233-234) and is the identity otherwise (no VAE, :235-236)."""
 
     @staticmethod
-    def forward(ctx, dec, target, mask, l1):
+    def forward(ctx, dec, target, mask, l1, clamp=True):
         dec, target = dec.contiguous(), target.contiguous()
         ctx.save_for_backward(dec, target, mask if mask is not None else torch.empty(0))
-        ctx.l1, ctx.has_mask = l1, mask is not None
-        return ops.pixel_loss(dec, target, mask, l1=l1)
+        ctx.l1, ctx.has_mask, ctx.clamp = l1, mask is not None, clamp
+        return ops.pixel_loss(dec, target, mask, l1=l1, clamp=clamp)
 
     @staticmethod
     def backward(ctx, gout):
         dec, target, mask = ctx.saved_tensors
-        return ops.pixel_loss_bwd(dec, target, mask if ctx.has_mask else None, gout, ctx.l1), None, None, None
+        return (ops.pixel_loss_bwd(dec, target, mask if ctx.has_mask else None, gout, ctx.l1, ctx.clamp), None, None,
+                None, None)
 
 
 class AxpyRowsFn(torch.autograd.Function):

@@ -828,18 +828,21 @@ extern "C" int lbmk_adamw(void* p, const void* g, float* m, float* v, int64_t n,
 }
 
 // ---- pixel reconstruction loss (src/lbm/models/lbm/lbm_model.py:197-249, l2 / l1 variants) -------------
-// per-sample mean of ((clamp(dec, -1, 1) - target) * mask)^2 or |.|, and its gradient w.r.t. dec
+// per-sample mean of ((c(dec) - target) * mask)^2 or |.|, and its gradient w.r.t. dec; c = clamp to [-1, 1] when
+// `clamp` is set (the reference clamps the VAE-decoded prediction only: with no VAE the raw prediction is compared)
 namespace {
 template <typename TP, typename TT>
 __global__ __launch_bounds__(1024) void pixel_loss_kernel(const TP* __restrict__ dec, const TT* __restrict__ tgt,
                                                           const uint8_t* __restrict__ mask, float* __restrict__ out,
-                                                          int64_t per_sample, int l1) {
+                                                          int64_t per_sample, int l1, int clamp) {
   __shared__ float red[16];
   const int64_t base = (int64_t)blockIdx.x * per_sample;
   float acc = 0.f;
   for (int64_t i = threadIdx.x; i < per_sample; i += 1024) {
     const float m = mask ? (mask[base + i] ? 1.f : 0.f) : 1.f;
-    const float d = (fminf(fmaxf((float)dec[base + i], -1.f), 1.f) - (float)tgt[base + i]) * m;
+    float x = (float)dec[base + i];
+    if (clamp) x = fminf(fmaxf(x, -1.f), 1.f);
+    const float d = (x - (float)tgt[base + i]) * m;
     acc += l1 ? fabsf(d) : d * d;
   }
   acc = wave_sum(acc);
@@ -855,25 +858,25 @@ __global__ __launch_bounds__(1024) void pixel_loss_kernel(const TP* __restrict__
 template <typename TP, typename TT>
 __global__ void pixel_loss_bwd_kernel(const TP* __restrict__ dec, const TT* __restrict__ tgt, const uint8_t* __restrict__ mask,
                                       const float* __restrict__ gout, TP* __restrict__ ddec, int64_t per_sample, int64_t total,
-                                      int l1) {
+                                      int l1, int clamp) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / per_sample);
   const float m = mask ? (mask[i] ? 1.f : 0.f) : 1.f;
   const float x = (float)dec[i];
-  const float inside = (x >= -1.f && x <= 1.f) ? 1.f : 0.f;      // clamp passes the gradient inside [-1, 1] only
-  const float d = (fminf(fmaxf(x, -1.f), 1.f) - (float)tgt[i]) * m;
+  const float inside = (!clamp || (x >= -1.f && x <= 1.f)) ? 1.f : 0.f;   // a clamp passes the gradient inside [-1, 1] only
+  const float d = ((clamp ? fminf(fmaxf(x, -1.f), 1.f) : x) - (float)tgt[i]) * m;
   const float g = gout[b] / (float)per_sample * inside;
   ddec[i] = (TP)(l1 ? g * m * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : g * 2.f * d * m);
 }
 }  // namespace
 
 extern "C" int lbmk_pixel_loss(const void* dec, const void* target, const uint8_t* mask, float* out, int B,
-                               int64_t per_sample, int l1, int dec_dtype, int tgt_dtype, void* stream) {
+                               int64_t per_sample, int l1, int clamp, int dec_dtype, int tgt_dtype, void* stream) {
   LBMK_REQUIRE(dec && target && out && B > 0 && per_sample > 0, "pixel_loss: arguments");
   hipStream_t s = (hipStream_t)stream;
 #define PL(TP, TT) hipLaunchKernelGGL((pixel_loss_kernel<TP, TT>), dim3(B), dim3(1024), 0, s, (const TP*)dec, (const TT*)target, \
-                                      mask, out, per_sample, l1)
+                                      mask, out, per_sample, l1, clamp)
   if (dec_dtype == 0 && tgt_dtype == 0) PL(__bf16, __bf16);
   else if (dec_dtype == 0 && tgt_dtype == 1) PL(__bf16, float);
   else if (dec_dtype == 1 && tgt_dtype == 0) PL(float, __bf16);
@@ -884,14 +887,14 @@ extern "C" int lbmk_pixel_loss(const void* dec, const void* target, const uint8_
 }
 
 extern "C" int lbmk_pixel_loss_bwd(const void* dec, const void* target, const uint8_t* mask, const float* gout,
-                                   void* ddec, int B, int64_t per_sample, int l1, int dec_dtype, int tgt_dtype,
-                                   void* stream) {
+                                   void* ddec, int B, int64_t per_sample, int l1, int clamp, int dec_dtype,
+                                   int tgt_dtype, void* stream) {
   LBMK_REQUIRE(dec && target && gout && ddec && B > 0 && per_sample > 0, "pixel_loss_bwd: arguments");
   const int64_t total = (int64_t)B * per_sample;
   dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
 #define PLB(TP, TT) hipLaunchKernelGGL((pixel_loss_bwd_kernel<TP, TT>), grid, dim3(256), 0, s, (const TP*)dec, (const TT*)target, \
-                                       mask, gout, (TP*)ddec, per_sample, total, l1)
+                                       mask, gout, (TP*)ddec, per_sample, total, l1, clamp)
   if (dec_dtype == 0 && tgt_dtype == 0) PLB(__bf16, __bf16);
   else if (dec_dtype == 0 && tgt_dtype == 1) PLB(__bf16, float);
   else if (dec_dtype == 1 && tgt_dtype == 0) PLB(float, __bf16);

@@ -26,4 +26,4 @@ class LatentsConcatEmbedder(BaseConditioner):
         for image_key in self.config.image_keys:
             outputs.append(vae.encode(batch[image_key]))
         outputs = torch.concat(outputs, dim=1)
-        return {self.dim2outputkey[outputs.dim()]: outputs}
+        return self.by_rank(outputs)

@@ -18,4 +18,4 @@ class RawConcatEmbedder(BaseConditioner):
         assert all(d == dims_list[0] for d in dims_list), "All images and masks must have the same dimensions."
         outputs = [batch[k] for k in self.config.mask_keys] + [batch[k] for k in self.config.image_keys]
         outputs = torch.concat(outputs, dim=1)
-        return {self.dim2outputkey[outputs.dim()]: outputs}
+        return self.by_rank(outputs)

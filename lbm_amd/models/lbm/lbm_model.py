@@ -10,8 +10,8 @@ additions (default ``None`` = draw exactly like the reference):
     timesteps of :134;
   * ``sample(..., eps_list=)`` — the per-step noise of lbm_model.py:350.
 
-Not on the HIP path yet (raise NotImplementedError): the pixel loss (VAE-decode backward +
-LPIPS, lbm_model.py:172-175) and gradient propagation through the denoiser.
+``loss.backward()`` runs the HIP backward kernels (lbm_amd/autograd.py), the pixel loss (l2 / l1 / LPIPS through
+the frozen VAE decoder, lbm_model.py:172-175, 197-249) included.
 """
 from typing import Any, Dict, List, Optional, Tuple, Union
 
@@ -168,17 +168,20 @@ class LBMModel(BaseModel):
         model_input = model_input[:, :, sl_h, sl_w].contiguous()
         if valid_mask is not None:
             valid_mask = valid_mask[:, :, sl_h, sl_w]
-        decoded = self.vae.decode(prediction) if self.vae is not None else prediction
+        # only a VAE-decoded prediction is clamped (lbm_model.py:233-236): the pixel-space refine model (no VAE)
+        # compares, and back-propagates through, the raw prediction
+        clamp = self.vae is not None
+        decoded = self.vae.decode(prediction) if clamp else prediction
         if self.pixel_loss_type == "lpips":
-            # lpips_loss(clamp(decoded) * mask, target * mask).mean() (lbm_model.py:248-249); clamp and mask are fused
+            # lpips_loss(decoded * mask, target * mask).mean() (lbm_model.py:248-249); clamp and mask are fused
             # into the network's input stage
             if self.lpips_loss is None:
                 raise NotImplementedError("pixel_loss_type 'lpips' needs pixel_loss_weight > 0 at construction")
-            return self.lpips_loss(decoded, model_input, mask=valid_mask, clamp0=True).mean()
+            return self.lpips_loss(decoded, model_input, mask=valid_mask, clamp0=clamp).mean()
         if self.pixel_loss_type not in ("l2", "l1"):
             raise NotImplementedError(f"pixel loss type {self.pixel_loss_type} not implemented")
         from ...autograd import PixelLossFn
-        return PixelLossFn.apply(decoded.contiguous(), model_input, valid_mask, self.pixel_loss_type == "l1")
+        return PixelLossFn.apply(decoded.contiguous(), model_input, valid_mask, self.pixel_loss_type == "l1", clamp)
 
     def _get_conditioning(self, batch: Dict[str, Any], ucg_keys: List[str] = None, set_ucg_rate_zero=False, *args, **kwargs):
         if self.conditioner is not None:

@@ -889,25 +889,26 @@ def _mask_u8(mask, like):
     return None if mask is None else mask.to(torch.uint8).expand_as(like).contiguous()
 
 
-def pixel_loss(dec, target, mask=None, l1: bool = False):
-    """per-sample mean of ((clamp(dec, -1, 1) - target) * mask)^2 or |.| -> f32 [B]"""
+def pixel_loss(dec, target, mask=None, l1: bool = False, clamp: bool = True):
+    """per-sample mean of ((c(dec) - target) * mask)^2 or |.| -> f32 [B]; c clips to [-1, 1] when ``clamp``"""
     _need_gpu(dec, target, mask)
     assert dec.shape == target.shape and dec.is_contiguous() and target.is_contiguous()
     B = dec.shape[0]
     out = torch.empty(B, dtype=torch.float32, device=dec.device)
     check(lib.lbmk_pixel_loss(dec.data_ptr(), target.data_ptr(), _ptr(_mask_u8(mask, dec)), out.data_ptr(), B,
-                              dec[0].numel(), 1 if l1 else 0, _dt(dec), _dt(target), _stream()), "lbmk_pixel_loss")
+                              dec[0].numel(), 1 if l1 else 0, 1 if clamp else 0, _dt(dec), _dt(target), _stream()),
+          "lbmk_pixel_loss")
     return out
 
 
-def pixel_loss_bwd(dec, target, mask, gout, l1: bool):
+def pixel_loss_bwd(dec, target, mask, gout, l1: bool, clamp: bool = True):
     _need_gpu(dec, target, gout)
     B = dec.shape[0]
     gout = gout.reshape(B).float().contiguous()
     ddec = torch.empty_like(dec)
     check(lib.lbmk_pixel_loss_bwd(dec.data_ptr(), target.data_ptr(), _ptr(_mask_u8(mask, dec)), gout.data_ptr(),
-                                  ddec.data_ptr(), B, dec[0].numel(), 1 if l1 else 0, _dt(dec), _dt(target), _stream()),
-          "lbmk_pixel_loss_bwd")
+                                  ddec.data_ptr(), B, dec[0].numel(), 1 if l1 else 0, 1 if clamp else 0, _dt(dec),
+                                  _dt(target), _stream()), "lbmk_pixel_loss_bwd")
     return ddec
 
 

@@ -240,7 +240,7 @@ def test_training_forward_loss(small_unet, cuda):
                               lambda s, t: dr.unet_forward(usd, SMALL_UNET, s, t), 0.005)
     with torch.no_grad():
         out = model({"source_image": zs.to(cuda), "target_image": z.to(cuda)}, bridge_eps=eps.to(cuda), timesteps=ts)
-    assert rel_l2(out["noisy_sample"], ref["noisy_sample"]) < 1e-6 or rel_l2(out["noisy_sample"], ref["noisy_sample"]) < 4e-3
+    assert rel_l2(out["noisy_sample"], ref["noisy_sample"]) < 4e-3      # interpolant of bf16 latents, f32 output
     assert torch.equal(out["noisy_sample"][1].cpu(), zs[1].float())       # t == 1000 -> exact source latent
     assert abs(float(out["loss"]) - float(ref["loss"])) / float(ref["loss"]) < 1e-2
     assert rel_l2(out["predicted_hr"], ref["predicted_hr"]) < 1e-2
