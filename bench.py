@@ -86,18 +86,83 @@ def cpu_baseline(model, threads):
                       f"~{n / dt * 5.33 / 23.25:.3f} images/s extrapolated by FLOPs)"}
 
 
+PMC_TRAFFIC_FILES = ("profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
+
+
 def pmc_traffic(args):
-    """HBM bytes per igemm launch from the committed rocprofv3 --pmc passes over this same command (counters cannot
-    be read from inside the run); None when the workload differs from the profiled one or the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_igemm_step_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    if rec.get("workload") != {"res": args.res, "batch": args.batch, "nfe": args.nfe}:
-        return None
-    return round(rec["traffic_bytes_per_launch"])
+    """HBM bytes per igemm launch, REPLAYED from the newest committed record of separate rocprofv3 --pmc passes over this
+    same command (hardware counters cannot be read from inside the run): (bytes, source file), or (None, None) when the
+    workload differs from the profiled one or no record exists."""
+    for rel in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                rec = json.load(f)
+        except OSError:
+            continue
+        if rec.get("workload") == {"res": args.res, "batch": args.batch, "nfe": args.nfe}:
+            return round(rec["traffic_bytes_per_launch"]), rel
+    return None, None
+
+
+# algorithmic forward FLOPs per image (FLOP = 2 * MAC), SDXL-style UNet + SD VAE: resolution -> (encode, unet, decode)
+FLOPS_T = {512: (1.117, 1.693, 2.515), 1024: (4.879, 7.898, 10.470), 2048: (26.113, 49.630, 94.23)}
+
+
+def _timed_steps(fn, steps, dist, device):
+    from lbm_amd import dist as D
+    torch.cuda.synchronize()
+    D.barrier(dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    D.barrier(dist)
+    torch.cuda.synchronize()
+    return D.max_over_ranks(time.perf_counter() - t0, dist, device)
+
+
+def extra_inference(model, device, rank, world, dist, res, batch, nfe, steps):
+    """one more inference configuration (per-GPU share of a BASELINE config), measured after the headline region"""
+    g = torch.Generator().manual_seed(99 + rank)
+    images = (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device)
+    eps = torch.randn(batch, 4, res // 8, res // 8, generator=g).to(BF).to(device)
+    out = one_step(model, images, eps, nfe)                      # warm-up at this shape
+    el = _timed_steps(lambda: one_step(model, images, eps, nfe), steps, dist, device)
+    assert bool(torch.isfinite(out.float()).all())
+    ips = batch * world * steps / el
+    enc, unet, dec = FLOPS_T[res]
+    tf = ips * (enc + nfe * unet + dec)
+    del images, eps, out
+    return {"workload": f"{res}x{res}, {nfe}-NFE, batch {batch}/GPU x{world}" + (", tiled decode (9 tiles/image)" if res > 1024 else ""),
+            "value": round(ips, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 1), "steps": steps,
+            "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / world / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+
+
+def extra_training(model, device, rank, world, dist, res, batch, steps):
+    """bridge-matching training step: two frozen VAE encodes, interpolant, UNet forward + backward, latent loss,
+    gradient exchange over RCCL when world > 1, fused AdamW.  7.31 TFLOP per 512x512 sample (2 * 1.117 + 3 * 1.693)."""
+    from lbm_amd.trainer import TrainingConfig, TrainingPipeline
+    model.train()
+    model.vae.freeze()
+    pipe = TrainingPipeline(model, TrainingConfig(learning_rate=4e-5, optimizer_name="AdamW", trainable_params=["denoiser.*"]),
+                            dist=dist)
+    pipe.configure_optimizers()
+    g = torch.Generator().manual_seed(4242 + rank)
+    batch_d = {"source_image": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device),
+               "source_image_paste": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device)}
+    for _ in range(2):
+        loss = pipe.fit_step(batch_d)["loss"]
+    el = _timed_steps(lambda: pipe.fit_step(batch_d), steps, dist, device)
+    assert bool(torch.isfinite(loss))
+    sps = batch * world * steps / el
+    enc, unet, _ = FLOPS_T[res]
+    tf = sps * (2 * enc + 3 * unet)
+    return {"workload": f"training step {res}x{res}, batch {batch}/GPU x{world}: 2 frozen VAE encodes + UNet fwd/bwd + latent loss + "
+                        f"{pipe.reducer.mode if dist is not None else 'no'} gradient exchange + AdamW",
+            "value": round(sps, 3), "unit": "samples/s", "ms_per_step": round(el / steps * 1e3, 1), "steps": steps,
+            "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / world / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
 
 
 def main():
@@ -110,6 +175,10 @@ def main():
     ap.add_argument("--nfe", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sub-records of the other BASELINE configs")
+    ap.add_argument("--extras-budget-s", type=float, default=420.0,
+                    help="wall-clock limit for everything after the headline region; on expiry the line is printed without "
+                         "what is missing and the process exits")
     args = ap.parse_args()
 
     from lbm_amd import dist as D
@@ -145,6 +214,40 @@ def main():
     assert out.shape == (args.batch, 3, args.res, args.res) and bool(torch.isfinite(out.float()).all())
     elapsed = D.max_over_ranks(elapsed, dist, device)
 
+    state = {"roofline": None, "secondary": None, "cpu": None, "extra": {}, "done": False}
+
+    def emit():
+        if rank != 0 or state["done"]:
+            return
+        state["done"] = True
+        total_images = args.batch * world * args.steps
+        line = {
+            "metric": f"images/sec ({args.res}^2, {args.nfe}-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": 1,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "ms_per_image": round(elapsed / total_images * 1e3 * world, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (uniform [-1,1] images, seeded random-init weights of the reference architecture)",
+            "config": {"workload": f"LBM inference {args.res}x{args.res}, {args.nfe}-NFE, SDXL-style UNet (2.43B) + SD VAE encode/decode, "
+                                   f"batch {args.batch}/GPU, data-parallel x{world}", "global_batch": args.batch * world,
+                       "flops_per_image_T": 23.25 if (args.res, args.nfe) == (1024, 1) else None},
+            "roofline": state["roofline"], "secondary_kernels": state["secondary"], "cpu_baseline": state["cpu"],
+            "extra": state["extra"] or None,
+        }
+        print(json.dumps(line), flush=True)
+
+    # everything below is measured AFTER the headline region; a watchdog bounds it so that a stall there (first
+    # multi-rank collective of the training record, a slow host) can never cost the headline line
+    import threading
+
+    def expire():
+        state["extra"]["aborted"] = f"post-headline measurements exceeded {args.extras_budget_s:.0f} s"
+        emit()
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_budget_s, expire)
+    watchdog.daemon = True
+    watchdog.start()
+
     roofline, cpu, secondary = None, None, None
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the implicit-GEMM conv / linear kernel: every launch of one extra, untimed
@@ -155,7 +258,9 @@ def main():
         tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args),
+                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args)[0],
+                    "traffic_source": (f"replayed constant from {pmc_traffic(args)[1]} (separate rocprofv3 --pmc passes over "
+                                       "this command; not measured in this run)") if pmc_traffic(args)[1] else None,
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
                     "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3)}
@@ -171,23 +276,23 @@ def main():
                 ach, peak, unit, bound = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
             secondary.append({"kernel": kind, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                               "frac": round(ach / peak, 4), "launches": n, "share_of_step_time": round(ms / step_ms, 3)})
+    state["roofline"], state["secondary"] = roofline, secondary
+    if not args.no_extras and (args.res, args.nfe) == (1024, 1):
+        # per-GPU shares of the other BASELINE configurations, every rank taking part (same barrier / max-over-ranks
+        # timing as the headline): C3 = 4-step sampling at 1024^2, C5 = 2048^2, C4 = the training step
+        for name, fn in (("nfe4_1024_b8", lambda: extra_inference(model, device, rank, world, dist, 1024, 8, 4, 2)),
+                         ("res2048_b8", lambda: extra_inference(model, device, rank, world, dist, 2048, 8, 1, 1)),
+                         ("train_512_b8", lambda: extra_training(model, device, rank, world, dist, 512, 8, 3))):
+            try:
+                state["extra"][name] = fn()
+            except Exception as err:          # an extra must never cost the headline line
+                state["extra"][name] = {"error": f"{type(err).__name__}: {err}"[:300]}
+                break
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(model, min(16, os.cpu_count() or 1))
-
-    if rank == 0:
-        total_images = args.batch * world * args.steps
-        line = {
-            "metric": f"images/sec ({args.res}^2, {args.nfe}-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
-            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "setup_passes": 1,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "ms_per_image": round(elapsed / total_images * 1e3 * world, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic (uniform [-1,1] images, seeded random-init weights of the reference architecture)",
-            "config": {"workload": f"LBM inference {args.res}x{args.res}, {args.nfe}-NFE, SDXL-style UNet (2.43B) + SD VAE encode/decode, "
-                                   f"batch {args.batch}/GPU, data-parallel x{world}", "global_batch": args.batch * world,
-                       "flops_per_image_T": 23.25 if (args.res, args.nfe) == (1024, 1) else None},
-            "roofline": roofline, "secondary_kernels": secondary, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
+        # the box's CPU share for a one-GPU job is 16 cores (os.cpu_count() reports the whole machine)
+        state["cpu"] = cpu_baseline(model, min(16, os.cpu_count() or 1))
+    watchdog.cancel()
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -6,7 +6,7 @@
  * reference call site (file:line, relative to the reference tree) whose
  * arithmetic it replaces.  Every function
  *   - takes raw device pointers, sizes and a hipStream_t (passed as void*),
- *   - never allocates, frees or synchronises,
+ *   - never allocates, frees or synchronises (the one exception exists in diagnostic builds only, see LBMK_DIAG),
  *   - returns LBMK_OK or an LBMK_ERR_* code (nothing is launched on error).
  * Activations are bf16 (raw uint16 bit patterns), channels-last (NHWC):
  * a [B][H][W][C] tensor is also the [B*H*W][C] token matrix.
@@ -84,11 +84,14 @@ int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
 int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int gn_groups);
 /* number of tile configurations; cfg i has block tile bm[i] x bn[i] */
 int lbmk_igemm_tiles(int* bm, int* bn, int cap);
-/* Diagnostics (no reference counterpart): tile ids 115 / 116 run the 512x128 / 256x256 tiles with in-kernel time
- * stamps; this copies out 8 x uint64 per workgroup (100 MHz wall-clock stamps at start, after set-up, first stage
- * landed, K loop done, epilogue issued, stores drained; shader-clock counter at the K loop's start and end).
- * Synchronises the device.  Returns the hipError_t of the copy. */
+#ifdef LBMK_DIAG
+/* Diagnostic builds only (make -C lbm_amd/csrc DIAG=1; absent from the product library; no reference counterpart):
+ * tile ids 115 / 116 run the 512x128 / 256x256 tiles with in-kernel time stamps; this copies out 8 x uint64 per
+ * workgroup (100 MHz wall-clock stamps at start, after set-up, first stage landed, K loop done, epilogue issued, stores
+ * drained; shader-clock counter at the K loop's start and end), nblocks <= 65536.  The one entry point that
+ * synchronises the device.  Returns the hipError_t of the copy. */
 int lbmk_debug_igemm_times(unsigned long long* host, int nblocks);
+#endif
 
 /* ------------------------------------------------------------------------
  * GroupNorm(+SiLU) over NHWC bf16.  Replaces torch.nn.GroupNorm(32, C, eps)

@@ -88,7 +88,6 @@ SIGNATURES = {
     "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "lbmk_sum_partials": (i32, [vp, vp, i64, i32, i32, vp]),
     "lbmk_gemm_tn": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "lbmk_debug_igemm_times": (i32, [vp, i32]),
     "lbmk_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_lpips_prep": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "lbmk_lpips_prep_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
@@ -111,6 +110,10 @@ SIGNATURES = {
     "lbmk_pixel_loss_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "lbmk_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
+
+# present only in diagnostic builds of the library (make DIAG=1)
+if hasattr(lib, "lbmk_debug_igemm_times"):
+    SIGNATURES["lbmk_debug_igemm_times"] = (i32, [vp, i32])
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)   # AttributeError here = header / library mismatch

@@ -21,9 +21,16 @@
 // issued, stores drained; slots 6 / 7 hold the shader-clock counter at the start / end of the K loop
 // (in-kernel clock = delta(6..7) / delta(2..3) * 100 MHz).  lbmk_debug_igemm_times() copies them out.
 // No stamp executes otherwise.
+// Only in builds made with -DLBMK_DIAG (make DIAG=1): the product library carries neither the 4 MB stamp array nor the
+// synchronising read-out.
+#ifdef LBMK_DIAG
 __device__ unsigned long long igemm_dbg[65536 * 8];
 #define DBG_T(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define DBG_C(i) do { if (STAMP && threadIdx.x == 0 && blockIdx.x < 65536) igemm_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DBG_T(i) do { } while (0)
+#define DBG_C(i) do { } while (0)
+#endif
 
 
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
@@ -644,9 +651,12 @@ void launch(const lbmk_igemm_desc& d, hipStream_t s) {
 }
 }  // namespace
 
+#ifdef LBMK_DIAG
 extern "C" int lbmk_debug_igemm_times(unsigned long long* host, int nblocks) {
+  if (!host || nblocks <= 0 || nblocks > 65536) return (int)hipErrorInvalidValue;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(igemm_dbg), (size_t)nblocks * 8 * 8);
 }
+#endif
 
 extern "C" int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int G) {
   if (M <= 0 || N <= 0 || OH <= 0 || OW <= 0 || G <= 0 || N % G || Cin % 64) return -1;
@@ -742,8 +752,10 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       }
     }
   }
+#ifdef LBMK_DIAG
   if (tile == 115) { launch<512, 128, 8, 2, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+#endif
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
   if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14 || tile == 15, "igemm: tile %d has no 64x64 wave strips", tile);

@@ -6,11 +6,11 @@ The reference warm-starts the denoiser from ``StableDiffusionPipeline.from_pretr
 Here ``backbone_signature`` may be a LOCAL directory in the diffusers layout
 (``unet/``, ``vae/``, ``scheduler/``): its UNet weights are then adapted exactly like the
 reference does (zero-padding ``conv_in`` / ``attn*.to_k|to_v`` to the new shapes, strict load).
-A hub name cannot be fetched offline: the architecture is built with random weights and a warning.
+A hub name cannot be fetched offline: the builders raise ``FileNotFoundError`` unless ``allow_random_init=True`` is
+passed, which builds the architectures with untrained weights (synthetic benchmarks, tests, or training from scratch).
 """
 import json
 import os
-import warnings
 from typing import List, Optional
 
 import torch
@@ -82,6 +82,7 @@ def _build_relight_model(
         cross_attention_dim=None,
         lighting_condition_weight: float = 1.0,
         concat_condition_weight: float = 1.0,
+        allow_random_init: bool = False,
 ) -> LBMModel:
     if conditioning_images_keys is None:
         conditioning_images_keys = ["shading", "normal"]
@@ -101,8 +102,11 @@ def _build_relight_model(
         ckpt_sd = StateDictAdapter()(model_state_dict=denoiser.state_dict(), checkpoint_state_dict=ckpt_sd,
                                      regex_keys=_ADAPT_KEYS, strategy="zeros")
         denoiser.load_state_dict(ckpt_sd, strict=True)
-    else:
-        warnings.warn(f"'{backbone_signature}' is not a local diffusers directory: the denoiser keeps its RANDOM initialisation")
+    elif not allow_random_init:
+        raise FileNotFoundError(
+            f"'{backbone_signature}' is not a local diffusers-layout directory (unet/ vae/ scheduler/) and hub downloads are "
+            "unavailable: the denoiser cannot be warm-started. Pass a local directory, or allow_random_init=True to keep "
+            "the UNTRAINED initialisation (synthetic runs, training from scratch).")
 
     conditioners = []
     if conditioning_images_keys != [] or conditioning_masks_keys != []:
@@ -115,7 +119,7 @@ def _build_relight_model(
     conditioner = ConditionerWrapper(conditioners=conditioners)
 
     vae = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version=backbone_signature, subfolder="vae",
-                                                              tiling_size=(128, 128)))
+                                                              tiling_size=(128, 128), allow_random_init=allow_random_init))
     vae.freeze()
     vae.to(torch.bfloat16)
 
@@ -128,8 +132,10 @@ def _build_relight_model(
 
     model = LBMModel(
         config, denoiser=denoiser,
-        training_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
-        sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
+        training_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(
+            backbone_signature, subfolder="scheduler", allow_random_init=allow_random_init),
+        sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(
+            backbone_signature, subfolder="scheduler", allow_random_init=allow_random_init),
         vae=vae, conditioner=conditioner).to(torch.bfloat16)
     return model
 
@@ -168,6 +174,7 @@ def build_filllight_refine_model(
         pixel_loss_weight: float = 1.0,
         latent_loss_type: str = "l2",
         latent_loss_weight: float = 1.0,
+        allow_random_init: bool = False,
 ) -> LBMModel:
     """Pixel-space refine model (relight.py:325-417): UNet2DModel [64, 128, 256, 256] on 6-channel inputs
     (bridge sample + raw rgb conditioning), no VAE."""
@@ -195,6 +202,8 @@ def build_filllight_refine_model(
         selected_timesteps=selected_timesteps, prob=prob, bridge_noise_sigma=bridge_noise_sigma)
     return LBMModel(
         config, denoiser=denoiser,
-        training_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
-        sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler"),
+        training_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(
+            backbone_signature, subfolder="scheduler", allow_random_init=allow_random_init),
+        sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler.from_pretrained(
+            backbone_signature, subfolder="scheduler", allow_random_init=allow_random_init),
         vae=None, conditioner=ConditionerWrapper(conditioners=conditioners)).to(torch.bfloat16)

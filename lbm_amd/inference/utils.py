@@ -32,6 +32,8 @@ def get_model(model_dir: str, save_dir: Optional[str] = None, torch_dtype: torch
     with open(os.path.join(model_dir, yaml_file[0]), "r") as f:
         config = yaml.safe_load(f)
 
+    # every weight, the VAE's included, comes from the checkpoint below (strict load): the modules may be built untrained
+    config.setdefault("allow_random_init", True)
     model = _get_model_from_config(**config, torch_dtype=torch_dtype)
 
     if len(safetensors_files) > 0:
@@ -83,8 +85,12 @@ def _get_model_from_config(
     latent_loss_weight: float = 1.0,
     pixel_loss_weight: float = 0.0,
     torch_dtype: torch.dtype = torch.bfloat16,
+    allow_random_init: bool = False,
     **kwargs,
 ):
+    """``backbone_signature`` names where the VAE and the scheduler configuration come from: a local diffusers-layout
+    directory, or — with ``allow_random_init=True`` — a known hub name whose VAE architecture is then built with
+    untrained weights (no network here; without the flag a hub name raises ``FileNotFoundError``)."""
     conditioners = []
     denoiser = DiffusersUNet2DCondWrapper(**sdxl_style_unet_kwargs(unet_input_channels, vae_num_channels)).to(torch_dtype)
 
@@ -95,7 +101,8 @@ def _get_model_from_config(
         conditioners.append(emb)
     conditioner = ConditionerWrapper(conditioners=conditioners)
 
-    vae_config = AutoencoderKLDiffusersConfig(version=backbone_signature, subfolder="vae", tiling_size=(128, 128))
+    vae_config = AutoencoderKLDiffusersConfig(version=backbone_signature, subfolder="vae", tiling_size=(128, 128),
+                                              allow_random_init=allow_random_init)
     vae = AutoencoderKLDiffusers(vae_config).to(torch_dtype)
     vae.freeze()
     vae.to(torch_dtype)
@@ -106,7 +113,8 @@ def _get_model_from_config(
         timestep_sampling=timestep_sampling, logit_mean=logit_mean, logit_std=logit_std,
         selected_timesteps=selected_timesteps, prob=prob, bridge_noise_sigma=bridge_noise_sigma)
 
-    sampling_noise_scheduler = FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler")
+    sampling_noise_scheduler = FlowMatchEulerDiscreteScheduler.from_pretrained(backbone_signature, subfolder="scheduler",
+                                                                               allow_random_init=allow_random_init)
 
     model = LBMModel(config, denoiser=denoiser, sampling_noise_scheduler=sampling_noise_scheduler, vae=vae,
                      conditioner=conditioner).to(torch_dtype)

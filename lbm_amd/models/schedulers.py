@@ -28,9 +28,12 @@ class FlowMatchEulerDiscreteScheduler:
         self.sigma_max = self.sigmas[0].item()
 
     @classmethod
-    def from_pretrained(cls, name_or_path=None, subfolder=None, **kw):
-        """The SD / SDXL scheduler JSONs only contribute num_train_timesteps=1000; a local
-        ``scheduler_config.json`` is honoured when present."""
+    def from_pretrained(cls, name_or_path=None, subfolder=None, allow_random_init: bool = False, **kw):
+        """A local ``<dir>/<subfolder>/scheduler_config.json`` is read for ``num_train_timesteps`` / ``shift``.  The
+        scheduler JSONs of the Stable Diffusion 1.x / SDXL repositories (the backbones the reference names) describe
+        other scheduler classes and contribute ``num_train_timesteps = 1000`` only, so those names give the default
+        schedule without any download.  Anything else raises ``FileNotFoundError`` (no network to look it up) unless
+        ``allow_random_init`` is set, which accepts the default schedule."""
         import json
         import os
         if name_or_path and os.path.isdir(name_or_path):
@@ -39,7 +42,12 @@ class FlowMatchEulerDiscreteScheduler:
                 with open(p) as f:
                     cfg = json.load(f)
                 return cls(num_train_timesteps=cfg.get("num_train_timesteps", 1000), shift=cfg.get("shift", 1.0))
-        return cls()
+        name = str(name_or_path or "").lower()
+        if name_or_path is None or allow_random_init or "stable-diffusion" in name:
+            return cls()
+        raise FileNotFoundError(f"scheduler config '{name_or_path}' is neither a local directory holding "
+                                f"{subfolder or '.'}/scheduler_config.json nor a known Stable Diffusion backbone name, and "
+                                "hub downloads are unavailable; pass allow_random_init=True to take the default schedule")
 
     @property
     def step_index(self):

@@ -25,7 +25,7 @@ class AutoencoderKLDiffusers(BaseModel):
         BaseModel.__init__(self, config)
         self.config = config
         self.vae_model = vae_model if vae_model is not None else AutoencoderKL.from_pretrained(
-            config.version, subfolder=config.subfolder, revision=config.revision)
+            config.version, subfolder=config.subfolder, revision=config.revision, allow_random_init=config.allow_random_init)
         self.tiling_size = config.tiling_size
         self.tiling_overlap = config.tiling_overlap
         self._get_properties()

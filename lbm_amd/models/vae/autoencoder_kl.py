@@ -200,6 +200,17 @@ _KNOWN_VAE_CONFIGS = {
 }
 
 
+def known_vae_config(name: str) -> dict:
+    """Architecture + scaling factor of the VAE that ships with a known backbone name."""
+    low = name.lower()
+    if "xl" in low:
+        return dict(_KNOWN_VAE_CONFIGS["sdxl"])
+    if "stable-diffusion" in low or low in ("sd", "sd15", "offline", "synthetic"):
+        return dict(_KNOWN_VAE_CONFIGS["sd"])
+    raise ValueError(f"'{name}' names no known backbone (Stable Diffusion 1.x / SDXL): its VAE configuration is unknown "
+                     "offline; pass a local diffusers-layout directory")
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
                  layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, shift_factor=None,
@@ -224,10 +235,13 @@ class AutoencoderKL(nn.Module):
         return 2 ** (len(self.config.block_out_channels) - 1)
 
     @classmethod
-    def from_pretrained(cls, version: str, subfolder: str = "", revision: str = "main", **kw) -> "AutoencoderKL":
-        """Loads ``<version>/<subfolder>/config.json`` + ``*.safetensors`` from a LOCAL directory in
-        the diffusers layout.  Hub names cannot be fetched here: for the two backbones the reference
-        uses, the architecture is built with random weights and a warning (synthetic benchmarks)."""
+    def from_pretrained(cls, version: str, subfolder: str = "", revision: str = "main", allow_random_init: bool = False,
+                        **kw) -> "AutoencoderKL":
+        """Loads ``<version>/<subfolder>/config.json`` + ``*.safetensors`` from a LOCAL directory in the diffusers layout.
+        There is no network here, so a hub name cannot be fetched: it raises ``FileNotFoundError`` — a model that silently
+        carried untrained weights would produce garbage images with exit status 0.  ``allow_random_init=True`` (synthetic
+        benchmarks, tests, or a caller that loads a full state dict right afterwards) builds the architecture of the
+        named backbone (the SD 1.x and SDXL VAEs, the two the reference uses) with untrained weights instead."""
         path = os.path.join(version, subfolder) if subfolder else version
         if os.path.isdir(path):
             with open(os.path.join(path, "config.json")) as f:
@@ -239,11 +253,12 @@ class AutoencoderKL(nn.Module):
                 raise ValueError(f"no .safetensors weights under {path}")
             model.load_state_dict(load_file(os.path.join(path, files[0])), strict=True)
             return model
-        import warnings
-        key = "sdxl" if "xl" in version.lower() else "sd"
-        warnings.warn(f"'{version}' is not a local directory and the hub is unreachable: building the "
-                      f"{key.upper()} VAE architecture with RANDOM weights")
-        return cls(**_KNOWN_VAE_CONFIGS[key])
+        if not allow_random_init:
+            raise FileNotFoundError(
+                f"VAE '{path}' is not a local diffusers-layout directory and hub downloads are unavailable. Pass a local "
+                "directory, or allow_random_init=True to build the architecture with UNTRAINED weights (synthetic runs, "
+                "or when a complete state dict is loaded afterwards).")
+        return cls(**known_vae_config(version))
 
     # ---- API as used by the reference wrapper (autoencoderKL.py:64,116,134) -----------------
     def encode(self, x: torch.Tensor) -> AutoencoderKLOutput:

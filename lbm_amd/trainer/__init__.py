@@ -1,7 +1,9 @@
+from .fit import checkpoint_name, fit, resolve_resume_checkpoint, resolve_task_dir
 from .training_config import TrainingConfig
 from .utils import StateDictAdapter, StateDictRenamer
 
-__all__ = ["TrainingConfig", "StateDictAdapter", "StateDictRenamer", "TrainingPipeline"]
+__all__ = ["TrainingConfig", "StateDictAdapter", "StateDictRenamer", "TrainingPipeline", "fit", "resolve_task_dir",
+           "resolve_resume_checkpoint", "checkpoint_name"]
 
 
 def __getattr__(name):

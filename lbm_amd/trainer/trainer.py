@@ -16,6 +16,7 @@ are large (128 MB default).  The optimizer is one fused AdamW kernel per group o
 """
 import importlib
 import logging
+import os
 import re
 import time
 from typing import Any, Dict, List, Optional
@@ -29,18 +30,59 @@ from .training_config import TrainingConfig
 BUCKET_BYTES = 128 << 20
 
 
-class FlatGroup:
-    """Parameters of one optimizer group re-homed into flat buffers (parameters become views)."""
+def merge_ranges(ranges):
+    """sorted, coalesced copy of a list of [start, end) ranges"""
+    out = []
+    for s, e in sorted(r for r in ranges if r[1] > r[0]):
+        if out and s <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], e)
+        else:
+            out.append([s, e])
+    return [tuple(r) for r in out]
 
-    def __init__(self, params: List[nn.Parameter], lr: float, bucket_bytes: int = BUCKET_BYTES):
+
+def intersect_ranges(a, b):
+    """intersection of two sorted, coalesced range lists"""
+    out, i, j = [], 0, 0
+    while i < len(a) and j < len(b):
+        s, e = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if s < e:
+            out.append((s, e))
+        if a[i][1] < b[j][1]:
+            i += 1
+        else:
+            j += 1
+    return out
+
+
+class FlatGroup:
+    """Parameters of one optimizer group re-homed into flat buffers (parameters become views).
+
+    ``shards`` > 1 lays the buckets out for a reduce-scatter / all-gather exchange: every bucket's length is a multiple
+    of 8 * shards elements (zero padding at its tail), so rank r owns the r-th equal slice of every bucket, each slice
+    starting on a 16-byte boundary."""
+
+    def __init__(self, params: List[nn.Parameter], lr: float, bucket_bytes: int = BUCKET_BYTES, shards: int = 1):
         self.params = list(params)[::-1]          # reverse registration order ~ order gradients become ready
         self.lr = lr
+        self.shards = max(1, int(shards))
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.device == dev and p.dtype == dt for p in self.params), "one device / dtype per group"
+        per = max(1, bucket_bytes // torch.empty((), dtype=dt).element_size())
+        unit = 8 * self.shards
+        # buckets: contiguous [start, end) ranges of the flat buffers, each covering whole parameters
         offs, n = [], 0
-        for p in self.params:
+        self.buckets, self.param_bucket = [], []
+        start, count = 0, 0
+        for i, p in enumerate(self.params):
             offs.append(n)
             n += (p.numel() + 7) // 8 * 8          # keep every view 16-byte aligned
+            self.param_bucket.append(len(self.buckets))
+            count += 1
+            if n - start >= per or i + 1 == len(self.params):
+                n = (n + unit - 1) // unit * unit
+                self.buckets.append((start, n, count))
+                start, count = n, 0
         self.numel = n
         self.flat = torch.zeros(n, dtype=dt, device=dev)
         self.grad = torch.zeros(n, dtype=dt, device=dev)
@@ -49,22 +91,23 @@ class FlatGroup:
             p.data = self.flat[o:o + p.numel()].view_as(p)
             p.grad = self.grad[o:o + p.numel()].view_as(p)
         self.offsets = offs
-        # buckets: contiguous [start, end) ranges of the flat gradient, each covering whole parameters
-        per = max(1, bucket_bytes // self.flat.element_size())
-        self.buckets, self.param_bucket = [], []
-        start, count = 0, 0
-        for i, (p, o) in enumerate(zip(self.params, offs)):
-            self.param_bucket.append(len(self.buckets))
-            count += 1
-            end = offs[i + 1] if i + 1 < len(offs) else n
-            if end - start >= per or i + 1 == len(offs):
-                self.buckets.append((start, end, count))
-                start, count = end, 0
         self.m = self.v = None
 
     def rebind_grads(self):
         for p, o in zip(self.params, self.offsets):
             p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def shard_of(self, bucket: int, rank: int):
+        """[start, end) of rank's slice of a bucket (the whole bucket when unsharded)"""
+        s, e, _ = self.buckets[bucket]
+        step = (e - s) // self.shards
+        return s + rank * step, s + (rank + 1) * step
+
+    def moment_offset(self, pos: int, bucket: int, rank: int) -> int:
+        """index into this rank's moment buffers of flat position ``pos`` inside its slice of ``bucket``: the slices of
+        consecutive buckets are stored back to back, so the buffers hold numel / shards elements"""
+        s, _, _ = self.buckets[bucket]
+        return s // self.shards + (pos - self.shard_of(bucket, rank)[0])
 
 
 class GradSink:
@@ -108,87 +151,189 @@ class GradSink:
         for p, f in zip(params, fresh):
             if f:
                 self.reducer.written.add(id(p))
-                self.reducer.param_ready(self.group, self.group.param_bucket[self.slot[id(p)][1]])
+                self.reducer.param_ready(self.group, self.slot[id(p)][1])
             elif self.reducer.dist is not None:
                 raise RuntimeError("a parameter used twice per step cannot take the direct gradient route under data parallelism")
 
 
 class GradReducer:
-    """Bucketed, overlapped data-parallel gradient all-reduce over the flat gradient buffers."""
+    """Bucketed, overlapped data-parallel gradient exchange over the flat gradient buffers.
 
-    def __init__(self, groups: List[FlatGroup], dist=None, direct_grads: bool = True):
+    ``mode="reduce_scatter"`` (default under data parallelism): a bucket is reduce-scattered as soon as its gradients
+    exist, so rank r ends the backward pass holding the summed gradient of ITS slice of every bucket; the optimizer
+    then updates only that slice (its moments exist only there) and the updated parameters are all-gathered.  On the
+    point-to-point xGMI mesh each phase moves (N-1)/N of the bytes once, where a ring all-reduce moves them twice
+    through one link, and the optimizer pass shrinks N-fold.  ``mode="all_reduce"`` keeps whole-buffer replicas.
+
+    The reducer also records which parameters received a gradient in the step (``touched``): like
+    ``torch.optim.AdamW``, the optimizer leaves the others alone (no weight decay, no moment decay)."""
+
+    def __init__(self, groups: List[FlatGroup], dist=None, direct_grads: bool = True, mode: str = "reduce_scatter"):
+        assert mode in ("reduce_scatter", "all_reduce")
         self.groups, self.dist = groups, dist
+        self.mode = mode if dist is not None else "all_reduce"
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        if self.mode == "reduce_scatter":
+            assert all(g.shards == self.world for g in groups), "FlatGroup(shards=world_size) is required"
         self.handles = []
         self._pending = {}
         self.active = False
         self.written = set()
-        for g in groups:
+        self.touched = [set() for _ in groups]
+        for gi, g in enumerate(groups):
             sink = GradSink(self, g) if direct_grads else None
-            for p, b in zip(g.params, g.param_bucket):
+            for pi, p in enumerate(g.params):
                 if sink is not None:
                     p._lbmk_grad_sink = sink
-                if dist is not None:
-                    p.register_post_accumulate_grad_hook(self._make_hook(g, b))
+                p.register_post_accumulate_grad_hook(self._make_hook(g, pi))
+        self._gindex = {id(g): gi for gi, g in enumerate(groups)}
 
-    def param_ready(self, group, bucket):
-        """one more parameter of ``bucket`` holds its final gradient: send the bucket when it is complete"""
+    def _send(self, group, bucket):
+        s, e, _ = group.buckets[bucket]
+        if self.mode == "reduce_scatter":
+            a, b = group.shard_of(bucket, self.rank)
+            self.handles.append(self.dist.reduce_scatter_tensor(group.grad[a:b], group.grad[s:e],
+                                                                op=self.dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(group.grad[s:e], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def param_ready(self, group, index):
+        """parameter ``index`` of ``group`` holds its final gradient: send its bucket when that is complete"""
+        if not self.active:
+            return
+        self.touched[self._gindex[id(group)]].add(index)
         if self.dist is None:
             return
+        bucket = group.param_bucket[index]
         left = self._pending[id(group)]
         left[bucket] -= 1
         if left[bucket] == 0:
-            s, e, _ = group.buckets[bucket]
-            self.handles.append(self.dist.all_reduce(group.grad[s:e], op=self.dist.ReduceOp.SUM, async_op=True))
+            self._send(group, bucket)
 
-    def _make_hook(self, group, bucket):
+    def _make_hook(self, group, index):
         def hook(_param):
-            self.param_ready(group, bucket)
+            self.param_ready(group, index)
         return hook
 
     def begin_step(self):
         self.handles = []
         self.written = set()
+        self.touched = [set() for _ in self.groups]
         self._pending = {id(g): [c for (_, _, c) in g.buckets] for g in self.groups}
         for g in self.groups:
             g.grad.zero_()
             g.rebind_grads()
         self.active = True
 
-    def finish(self) -> float:
-        """Waits for every bucket; returns the factor that turns the summed gradient into the mean."""
+    def finish(self, loss: Optional[torch.Tensor] = None):
+        """Sends what is left, waits for every bucket, and agrees across ranks on which parameters were touched.
+        Returns (factor that turns the summed gradient into the mean, per-group update ranges in flat coordinates
+        restricted to this rank's slices, loss averaged over the ranks or None)."""
         self.active = False
-        if self.dist is None:
-            return 1.0
-        # parameters that received no gradient this step never fired their hook: reduce what is left
+        mean_loss = None if loss is None else loss.detach().float()
+        if self.dist is not None:
+            # parameters that received no gradient this step never fired their hook: exchange what is left
+            for g in self.groups:
+                left = self._pending[id(g)]
+                for b, c in enumerate(left):
+                    if c > 0:
+                        self._send(g, b)
+                        left[b] = 0
+            # one small vector: a flag per parameter (received a gradient on this rank) + the local loss
+            # (the reference logs the loss with sync_dist=True, src/lbm/trainer/trainer.py:220-227)
+            dev = self.groups[0].flat.device
+            flags = torch.zeros(sum(len(g.params) for g in self.groups) + 1, dtype=torch.float32)
+            base = 0
+            for gi, g in enumerate(self.groups):
+                for i in self.touched[gi]:
+                    flags[base + i] = 1.0
+                base += len(g.params)
+            flags = flags.to(dev)
+            if mean_loss is not None:
+                flags[-1] = mean_loss.reshape(()).to(dev)
+            self.dist.all_reduce(flags, op=self.dist.ReduceOp.SUM)
+            host = flags.cpu()
+            base = 0
+            for gi, g in enumerate(self.groups):
+                self.touched[gi] = {i for i in range(len(g.params)) if host[base + i] > 0}
+                base += len(g.params)
+            if mean_loss is not None:
+                mean_loss = host[-1] / self.world
+            for h in self.handles:
+                h.wait()
+        ranges = []
+        for gi, g in enumerate(self.groups):
+            if len(self.touched[gi]) == len(g.params):
+                mine = [(0, g.numel)]
+            else:
+                mine = merge_ranges([(g.offsets[i], g.offsets[i] + (g.params[i].numel() + 7) // 8 * 8)
+                                     for i in self.touched[gi]])
+            if self.mode == "reduce_scatter":
+                mine = intersect_ranges(mine, [g.shard_of(b, self.rank) for b in range(len(g.buckets))])
+            ranges.append(mine)
+        return 1.0 / self.world, ranges, mean_loss
+
+    def gather_params(self):
+        """reduce_scatter mode: every rank updated its slices only; collect the others' (in place)"""
+        if self.mode != "reduce_scatter":
+            return
+        hs = []
         for g in self.groups:
-            left = self._pending[id(g)]
-            for b, c in enumerate(left):
-                if c > 0:
-                    s, e, _ = g.buckets[b]
-                    self.handles.append(self.dist.all_reduce(g.grad[s:e], op=self.dist.ReduceOp.SUM, async_op=True))
-                    left[b] = 0
-        for h in self.handles:
+            for b, (s, e, _) in enumerate(g.buckets):
+                a, c = g.shard_of(b, self.rank)
+                hs.append(self.dist.all_gather_into_tensor(g.flat[s:e], g.flat[a:c], async_op=True))
+        for h in hs:
             h.wait()
-        return 1.0 / self.dist.get_world_size()
+
+    def broadcast_params(self):
+        """replicas start identical: rank 0's flat parameter buffers win (what DDP does at construction)"""
+        if self.dist is None:
+            return
+        for g in self.groups:
+            self.dist.broadcast(g.flat, src=0)
 
 
 class HipAdamW:
-    """torch.optim.AdamW semantics on flat buffers, one fused kernel launch per group."""
+    """torch.optim.AdamW semantics on flat buffers: one fused kernel launch per contiguous range to update (the whole
+    buffer when every parameter received a gradient and the buffers are replicated).  With ``shards`` > 1 the moment
+    buffers hold only this rank's slice of every bucket (numel / shards elements)."""
 
-    def __init__(self, groups: List[FlatGroup], betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **unused):
+    def __init__(self, groups: List[FlatGroup], betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, rank: int = 0,
+                 sharded: bool = False, **unused):
         self.groups, self.betas, self.eps, self.weight_decay = groups, tuple(betas), eps, weight_decay
+        self.rank, self.sharded = rank, sharded
         self.step_count = 0
         self.param_groups = [{"params": g.params, "lr": g.lr} for g in groups]
         for g in groups:
-            g.m = torch.zeros(g.numel, dtype=torch.float32, device=g.flat.device)
-            g.v = torch.zeros(g.numel, dtype=torch.float32, device=g.flat.device)
+            n = g.numel // g.shards if sharded else g.numel
+            g.m = torch.zeros(n, dtype=torch.float32, device=g.flat.device)
+            g.v = torch.zeros(n, dtype=torch.float32, device=g.flat.device)
 
-    def step(self, grad_scale: float = 1.0):
+    def _moment_range(self, g, s, e):
+        if not self.sharded:
+            return s, e
+        # a range handed over by GradReducer.finish lies inside one of this rank's bucket slices
+        for b in range(len(g.buckets)):
+            a, c = g.shard_of(b, self.rank)
+            if a <= s and e <= c:
+                o = g.moment_offset(s, b, self.rank)
+                return o, o + (e - s)
+        raise AssertionError("update range outside this rank's slices")
+
+    def step(self, grad_scale: float = 1.0, ranges=None):
         self.step_count += 1
-        for g, pg in zip(self.groups, self.param_groups):
-            ops.adamw_step(g.flat, g.grad, g.m, g.v, lr=pg["lr"], betas=self.betas, eps=self.eps,
-                           weight_decay=self.weight_decay, step=self.step_count, grad_scale=grad_scale)
-            for p in g.params:                      # the kernel wrote through raw pointers: invalidate cached packs
+        for gi, (g, pg) in enumerate(zip(self.groups, self.param_groups)):
+            todo = [(0, g.numel)] if ranges is None else ranges[gi]
+            for s, e in todo:
+                ms, me = self._moment_range(g, s, e)
+                ops.adamw_step(g.flat[s:e], g.grad[s:e], g.m[ms:me], g.v[ms:me], lr=pg["lr"], betas=self.betas,
+                               eps=self.eps, weight_decay=self.weight_decay, step=self.step_count, grad_scale=grad_scale)
+
+    def invalidate(self):
+        """the kernel (and the all-gather) wrote parameters through raw pointers: invalidate cached weight packs"""
+        for g in self.groups:
+            for p in g.params:
                 torch.autograd.graph.increment_version(p)
 
     def zero_grad(self, set_to_none: bool = False):
@@ -206,8 +351,14 @@ class HipAdamW:
 
 
 class TrainingPipeline(nn.Module):
-    def __init__(self, model, pipeline_config: TrainingConfig, verbose: bool = False, dist=None, **kwargs):
+    def __init__(self, model, pipeline_config: TrainingConfig, verbose: bool = False, dist=None,
+                 grad_exchange: Optional[str] = None, bucket_bytes: int = BUCKET_BYTES, **kwargs):
+        """``dist``: ``torch.distributed`` (initialised) for data-parallel training, else None.  ``grad_exchange``:
+        "reduce_scatter" (default; environment LBM_GRAD_EXCHANGE overrides) or "all_reduce" — see GradReducer."""
         super().__init__()
+        self.grad_exchange = grad_exchange or os.environ.get("LBM_GRAD_EXCHANGE", "reduce_scatter")
+        self.bucket_bytes = bucket_bytes
+        self.last_loss_mean: Optional[torch.Tensor] = None
         self.model = model
         self.pipeline_config = pipeline_config
         self.log_samples_model_kwargs = pipeline_config.log_samples_model_kwargs
@@ -245,9 +396,17 @@ class TrainingPipeline(nn.Module):
         logging.info(f"trainable params: {n_params}")
         kwargs = dict(self.pipeline_config.optimizer_kwargs or {})
         if self.pipeline_config.optimizer_name == "AdamW":
-            flat = [FlatGroup(ps, lr * lr_mult.get(rx, 1.0)) for rx, ps in groups.items() if ps]
-            optimizer = HipAdamW(flat, **kwargs)
-            self.reducer = GradReducer(flat, self.dist)
+            sharded = self.dist is not None and self.grad_exchange == "reduce_scatter"
+            world = self.dist.get_world_size() if self.dist is not None else 1
+            flat = [FlatGroup(ps, lr * lr_mult.get(rx, 1.0), self.bucket_bytes, shards=world if sharded else 1)
+                    for rx, ps in groups.items() if ps]
+            self.reducer = GradReducer(flat, self.dist, mode=self.grad_exchange)
+            optimizer = HipAdamW(flat, rank=self.reducer.rank, sharded=sharded, **kwargs)
+            # replicas must start identical (Lightning's DDP strategy broadcasts rank 0's module state): flat buffers
+            # of the trainable groups, then every other parameter and buffer (frozen VAE, num_iterations, Fourier B)
+            self.reducer.broadcast_params()
+            self._broadcast_rest({id(p) for g in flat for p in g.params})
+            optimizer.invalidate()
         else:
             # other torch.optim classes keep torch's own update rule; gradients are still reduced here
             param_groups = [{"params": ps, "lr": lr * lr_mult.get(rx, 1.0)} for rx, ps in groups.items() if ps]
@@ -255,6 +414,13 @@ class TrainingPipeline(nn.Module):
             self.reducer = None
         self.optims = [optimizer]
         return [optimizer]
+
+    def _broadcast_rest(self, skip_ids):
+        if self.dist is None:
+            return
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            if id(t) not in skip_ids and t.numel() > 0 and t.device.type != "meta":
+                self.dist.broadcast(t.data, src=0)
 
     def training_step(self, train_batch: Dict[str, Any], batch_idx: int) -> dict:
         model_output = self.model(train_batch)
@@ -277,7 +443,11 @@ class TrainingPipeline(nn.Module):
                 self.reducer.active = False      # no direct gradient writes outside a step
             raise
         if self.reducer is not None:
-            opt.step(grad_scale=self.reducer.finish())
+            scale, ranges, loss_mean = self.reducer.finish(out["loss"])
+            opt.step(grad_scale=scale, ranges=ranges)
+            self.reducer.gather_params()
+            opt.invalidate()
+            self.last_loss_mean = loss_mean          # 0-dim tensor (on the host under data parallelism): no extra sync
         else:
             if self.dist is not None:
                 world = self.dist.get_world_size()
@@ -290,23 +460,52 @@ class TrainingPipeline(nn.Module):
         self.global_step += 1
         if hasattr(self.model, "on_train_batch_end"):
             self.model.on_train_batch_end(train_batch)
-        return {"loss": out["loss"].detach(), "batch_idx": out["batch_idx"]}
+        # "loss_mean": the step's loss averaged over the data-parallel ranks (the reference logs train/loss with
+        # sync_dist=True); equals the local loss in a single process
+        return {"loss": out["loss"].detach(), "batch_idx": out["batch_idx"], "loss_mean": self.last_loss_mean}
 
     # ---- checkpoints (what Lightning's ModelCheckpoint / resume do in examples/training/train_base.py:27-53) ----
-    def save_checkpoint(self, path: str):
+    def save_checkpoint(self, path: str, write: bool = True):
         """Lightning-layout ``.ckpt``: ``state_dict`` keys carry the ``model.`` prefix (so ``get_model`` loads the
-        file), plus the optimizer moments and the step counter.  Tensors only: loadable with weights_only=True."""
+        file), plus the optimizer moments and the step counter.  Tensors only: loadable with weights_only=True.
+        Under data parallelism with sharded moments every rank must call this (the moments are gathered);
+        ``write=False`` on the ranks that should not write the file."""
         ckpt = {"state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
                 "global_step": self.global_step}
         if self.optims:
             opt = self.optims[0]
             sd = opt.state_dict()
             if isinstance(opt, HipAdamW):
-                ckpt["optimizer_states"] = [{"step": sd["step"], "m": [t.cpu() for t in sd["m"]], "v": [t.cpu() for t in sd["v"]],
+                ckpt["optimizer_states"] = [{"step": sd["step"], "m": [self._full_moments(g, g.m).cpu() for g in opt.groups],
+                                             "v": [self._full_moments(g, g.v).cpu() for g in opt.groups],
                                              "numel": [g.numel for g in opt.groups]}]
             else:
                 ckpt["optimizer_states"] = [sd]
-        torch.save(ckpt, path)
+        if write:
+            torch.save(ckpt, path)
+
+    def _sharded(self) -> bool:
+        return self.reducer is not None and self.reducer.mode == "reduce_scatter"
+
+    def _full_moments(self, g: "FlatGroup", mine: torch.Tensor) -> torch.Tensor:
+        """moment buffer in flat-parameter coordinates (checkpoints are independent of the exchange mode and of the
+        number of ranks that wrote them); every rank must call this when the moments are sharded"""
+        if not self._sharded():
+            return mine
+        full = torch.zeros(g.numel, dtype=mine.dtype, device=mine.device)
+        rank = self.reducer.rank
+        for b, (s, e, _) in enumerate(g.buckets):
+            a, c = g.shard_of(b, rank)
+            o = g.moment_offset(a, b, rank)
+            full[a:c] = mine[o:o + (c - a)]
+            self.dist.all_gather_into_tensor(full[s:e], full[a:c].clone())
+        return full
+
+    def _my_moments(self, g: "FlatGroup", full: torch.Tensor) -> torch.Tensor:
+        if not self._sharded():
+            return full
+        rank = self.reducer.rank
+        return torch.cat([full[slice(*g.shard_of(b, rank))] for b in range(len(g.buckets))])
 
     def load_checkpoint(self, path: str, strict: bool = True):
         """Restores parameters in place (they stay views of the flat buffers), optimizer state and the step."""
@@ -332,7 +531,8 @@ class TrainingPipeline(nn.Module):
             if isinstance(opt, HipAdamW):
                 st = states[0]
                 assert st["numel"] == [g.numel for g in opt.groups], "optimizer groups differ from the checkpoint's"
-                opt.load_state_dict({"step": st["step"], "m": st["m"], "v": st["v"]})
+                opt.load_state_dict({"step": st["step"], "m": [self._my_moments(g, t) for g, t in zip(opt.groups, st["m"])],
+                                     "v": [self._my_moments(g, t) for g, t in zip(opt.groups, st["v"])]})
             else:
                 opt.load_state_dict(states[0])
 

@@ -7,7 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = build_filllight_refine_model(backbone_signature="offline", pixel_loss_weight=0.0, bridge_noise_sigma=0.005).to(dev)
+model = build_filllight_refine_model(backbone_signature="offline", allow_random_init=True, pixel_loss_weight=0.0, bridge_noise_sigma=0.005).to(dev)
 src = (torch.rand(B, 3, res, res) * 2 - 1).to(torch.bfloat16).to(dev)
 for _ in range(2):
     out = model.sample(src, num_steps=1, conditioner_inputs={"rgb": src})

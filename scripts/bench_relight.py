@@ -9,7 +9,7 @@ res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 nfe = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = build_relight_model(backbone_signature="offline", unet_input_channels=12, bridge_noise_sigma=0.005).to(torch.bfloat16).to(dev)
+model = build_relight_model(backbone_signature="offline", allow_random_init=True, unet_input_channels=12, bridge_noise_sigma=0.005).to(torch.bfloat16).to(dev)
 model.eval()
 g = torch.Generator().manual_seed(1)
 imgs = {k: (torch.rand(B, 3, res, res, generator=g) * 2 - 1).to(torch.bfloat16).to(dev) for k in ("source", "shading", "normal")}

@@ -31,7 +31,7 @@ def main():
     from lbm_amd.trainer import TrainingConfig, TrainingPipeline
     torch.manual_seed(0)
     model = build_filllight_model(
-        backbone_signature="offline", unet_input_channels=5, timestep_sampling="custom_timesteps",
+        backbone_signature="offline", allow_random_init=True, unet_input_channels=5, timestep_sampling="custom_timesteps",
         selected_timesteps=[250, 500, 750, 1000], prob=[0.25, 0.25, 0.25, 0.25],
         pixel_loss_type=args.pixel_loss if args.pixel_loss != "none" else "l2",
         pixel_loss_weight=0.0 if args.pixel_loss == "none" else 1.0, latent_loss_type="l2", latent_loss_weight=1.0,

@@ -1,4 +1,6 @@
-"""In-kernel wall-clock stamps of the 16-wave tiles (diagnostic build only)."""
+"""In-kernel wall-clock stamps of the 16-wave tiles.  Needs a diagnostic build of the library:
+`make -C lbm_amd/csrc clean && make -C lbm_amd/csrc DIAG=1 -j8` (the product build has neither tile ids 115 / 116 nor
+lbmk_debug_igemm_times)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -524,6 +524,57 @@ def test_training_checkpoint_resume(cuda, tmp_path):
     assert all(k.startswith("model.") for k in sd) and "model.denoiser.conv_in.weight" in sd
 
 
+def test_fit_loop_resume_and_rccl_exchange(cuda, tmp_path):
+    """lbm_amd.trainer.fit: 4 steps straight through == 2 steps, stop, resume from the checkpoint the resolver picks,
+    2 more steps (bit-identical parameters); then the same 4 steps through a one-rank RCCL process group with the
+    reduce-scatter -> sharded AdamW -> all-gather exchange give the same parameters as without a process group
+    (with one rank the collectives are copies, so any difference would be a bookkeeping error)."""
+    import socket
+    import torch.distributed as dist
+    from lbm_amd.trainer import TrainingConfig, TrainingPipeline, fit, resolve_resume_checkpoint, resolve_task_dir
+    cfg = TrainingConfig(learning_rate=1e-3, optimizer_name="AdamW", trainable_params=["denoiser.*"])
+    g = torch.Generator().manual_seed(5)
+    batches = [{"target": torch.randn(2, 4, 32, 32, generator=g).to(BF), "source": torch.randn(2, 4, 32, 32, generator=g).to(BF)}
+               for _ in range(4)]
+    eps = torch.randn(2, 4, 32, 32, generator=g).to(BF).to(cuda)
+    ts = torch.tensor([500, 750], device=cuda)
+
+    def make(d=None, **kw):
+        model = _toy_lbm(cuda)
+        orig = model.forward
+        model.forward = lambda batch, *a, **k: orig(batch, bridge_eps=eps, timesteps=ts)
+        pipe = TrainingPipeline(model, cfg, dist=d, **kw)
+        pipe.configure_optimizers()
+        return model, pipe
+
+    to_dev = lambda b: {k: v.to(cuda) for k, v in b.items()}
+    model_a, pipe_a = make()
+    assert fit(pipe_a, batches, max_epochs=1, to_device=to_dev) == 4
+    task = resolve_task_dir(str(tmp_path), "toy")
+    model_b, pipe_b = make()
+    fit(pipe_b, batches[:2], max_epochs=1, save_dir=task, save_interval=2, to_device=to_dev)
+    ckpt = resolve_resume_checkpoint(task, True)
+    assert ckpt is not None and ckpt.endswith("epoch=0-step=2.ckpt")
+    model_c, pipe_c = make()
+    assert fit(pipe_c, batches[2:], max_epochs=1, ckpt_path=ckpt, to_device=to_dev) == 4
+    for (n1, p1), (_, p2) in zip(model_a.named_parameters(), model_c.named_parameters()):
+        assert torch.equal(p1, p2), n1
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=cuda)
+    try:
+        model_d, pipe_d = make(dist, grad_exchange="reduce_scatter", bucket_bytes=1 << 16)
+        assert len(pipe_d.optims[0].groups[0].buckets) > 3
+        outs = [pipe_d.fit_step(to_dev(b)) for b in batches]
+        torch.cuda.synchronize()
+        assert abs(float(outs[-1]["loss_mean"]) - float(outs[-1]["loss"])) < 1e-6
+    finally:
+        dist.destroy_process_group()
+    for (n1, p1), (_, p2) in zip(model_a.named_parameters(), model_d.named_parameters()):
+        assert torch.equal(p1, p2), n1
+
+
 @pytest.mark.parametrize("mode", ["relight_self_attn", "filllight_cross_attn"])
 def test_unet_sd15_style_gradients(cuda, mode):
     """SD1.5-style UNet (1x1-conv projections, head dims 40 / 80): parameter gradients against fp32 autograd through

@@ -82,11 +82,11 @@ def _reducer_worker(rank, world, port, q):
     unused = torch.nn.Parameter(torch.zeros(5))               # never receives a gradient
     params = list(net.parameters()) + [unused]
     grp = FlatGroup(params, lr=1e-3, bucket_bytes=64)          # several small buckets
-    red = GradReducer([grp], dist)
+    red = GradReducer([grp], dist, mode="all_reduce")
     x = torch.randn(6, 16, generator=torch.Generator().manual_seed(100 + rank))
     red.begin_step()
     net(x).pow(2).sum().backward()
-    scale = red.finish()
+    scale = red.finish()[0]
     flat_mean = grp.grad * scale
     # reference: gradients of both ranks' inputs computed locally
     ref = torch.zeros_like(grp.grad)
@@ -121,7 +121,7 @@ def _reducer_worker(rank, world, port, q):
     h = DirectLinear.apply(h, net[2].weight, net[2].bias)
     net[3](h).pow(2).sum().backward()
     n_direct = len(red.written)
-    scale = red.finish()
+    scale = red.finish()[0]
     err_direct = float((grp.grad * scale - ref).abs().max())
     assert not red.active
     q.put((rank, len(grp.buckets), float((flat_mean - ref).abs().max()), bool(all(p.data_ptr() >= grp.flat.data_ptr() for p in grp.params)),
@@ -148,3 +148,102 @@ def test_bucketed_gradient_allreduce_world2():
         assert err < 1e-5
         assert views
         assert n_direct == 2 and err_direct < 1e-5
+
+
+def _torch_adamw_step(p_flat, g_flat, m, v, *, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, step=1, grad_scale=1.0):
+    """CPU stand-in for the fused AdamW kernel (torch.optim.AdamW's update rule on a flat range)"""
+    g = g_flat.float() * grad_scale
+    p = p_flat.float() * (1 - lr * weight_decay)
+    m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    mhat, vhat = m / (1 - betas[0] ** step), v / (1 - betas[1] ** step)
+    p_flat.copy_((p - lr * mhat / (vhat.sqrt() + eps)).to(p_flat.dtype))
+
+
+def _exchange_worker(rank, world, port, q, mode):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys, types
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = types.ModuleType("lbm_amd"); pkg.__path__ = [os.path.join(os.path.dirname(os.path.dirname(__file__)), "lbm_amd")]
+    sys.modules.setdefault("lbm_amd", pkg)
+    ops = types.ModuleType("lbm_amd.ops")
+    ops.adamw_step = _torch_adamw_step
+    sys.modules["lbm_amd.ops"] = ops
+    sys.modules["lbm_amd"].ops = ops
+    from lbm_amd.trainer.trainer import TrainingPipeline
+    from lbm_amd.trainer.training_config import TrainingConfig
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Linear(16, 40), torch.nn.ReLU(), torch.nn.Linear(40, 24),
+                                            torch.nn.ReLU(), torch.nn.Linear(24, 4))
+            self.unused = torch.nn.Parameter(torch.full((11,), 0.5))       # never receives a gradient
+            self.register_buffer("stat", torch.randn(3))
+
+        def forward(self, batch):
+            return {"loss": self.body(batch["x"]).pow(2).mean()}
+
+    torch.manual_seed(1000 + rank)            # deliberately different initialisation per rank
+    net = Net()
+    pipe = TrainingPipeline(net, TrainingConfig(learning_rate=1e-2, optimizer_name="AdamW", trainable_params=["body.*", "unused"]),
+                            dist=dist, grad_exchange=mode, bucket_bytes=1024)
+    pipe.configure_optimizers()
+    # after configure_optimizers every replica equals rank 0's initialisation, buffers included
+    torch.manual_seed(1000)
+    ref = Net()
+    same_start = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    opt = torch.optim.AdamW([p for p in ref.parameters()], lr=1e-2)
+    losses = []
+    for step in range(3):
+        xs = [torch.randn(5, 16, generator=torch.Generator().manual_seed(7 * step + r)) for r in range(world)]
+        out = pipe.fit_step({"x": xs[rank]})
+        losses.append(float(out["loss_mean"]))
+        opt.zero_grad(set_to_none=True)
+        ref_loss = sum(ref({"x": x})["loss"] for x in xs) / world
+        ref_loss.backward()
+        opt.step()
+        losses[-1] -= float(ref_loss.detach())
+    err = max(float((a - b).abs().max()) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    g = pipe.optims[0].groups[0]
+    q.put((rank, same_start, err, max(abs(l) for l in losses), float(net.unused.detach().sub(0.5).abs().max()),
+           len(g.buckets), g.m.numel(), g.numel))
+    dist.destroy_process_group()
+
+
+def _run_exchange(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_reduce_scatter_all_gather_training_world2():
+    """three data-parallel AdamW steps through TrainingPipeline.fit_step on gloo with the reduce-scatter -> sharded
+    AdamW -> all-gather exchange: replicas are broadcast from rank 0, end equal to a single-process torch.optim.AdamW
+    on the mean gradient, the parameter that never gets a gradient is left alone (no weight decay), the logged loss
+    is the mean over ranks, and every rank keeps moments for its half of the buffer only"""
+    for rank, same_start, err, loss_err, unused_drift, nbuckets, m_numel, numel in _run_exchange("reduce_scatter"):
+        assert same_start
+        assert err < 1e-5, err
+        assert loss_err < 1e-6
+        assert unused_drift == 0.0
+        assert nbuckets >= 2 and m_numel * 2 == numel
+
+
+def test_all_reduce_training_world2():
+    """same steps with whole-buffer all-reduce (the switchable fallback)"""
+    for rank, same_start, err, loss_err, unused_drift, nbuckets, m_numel, numel in _run_exchange("all_reduce"):
+        assert same_start and err < 1e-5 and loss_err < 1e-6 and unused_drift == 0.0
+        assert m_numel == numel

@@ -35,9 +35,9 @@ def test_relight_builders_structure():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         with torch.device("meta"):
-            m = build_relight_model(unet_input_channels=12, bridge_noise_sigma=0.005, timestep_sampling="custom_timesteps",
+            m = build_relight_model(allow_random_init=True, unet_input_channels=12, bridge_noise_sigma=0.005, timestep_sampling="custom_timesteps",
                                     selected_timesteps=[250.0, 500.0, 750.0, 1000.0], prob=[0.25, 0.25, 0.25, 0.25])
-            f = build_filllight_model(unet_input_channels=9, conditioning_images_keys=["shading"],
+            f = build_filllight_model(allow_random_init=True, unet_input_channels=9, conditioning_images_keys=["shading"],
                                       lighting_embedder_config=dict(seq_len=5, param_groups=[[0, 1], [2], [3, 4, 5], [6], [7]]))
     assert sum(p.numel() for p in m.denoiser.parameters()) == 865_155_524
     assert isinstance(m.conditioner.conditioners[0], LatentsConcatEmbedder)
@@ -54,6 +54,57 @@ def test_relight_builders_structure():
     with torch.device("meta"):
         rf = build_filllight_refine_model()
     assert sum(p.numel() for p in rf.denoiser.parameters()) == 23_988_291
+
+
+def test_hub_names_raise_without_allow_random_init(tmp_path):
+    """no network: a hub name must not silently become a randomly initialised model"""
+    from lbm_amd.inference import build_filllight_model, build_filllight_refine_model, build_relight_model
+    from lbm_amd.inference.utils import _get_model_from_config
+    from lbm_amd.models.schedulers import FlowMatchEulerDiscreteScheduler
+    from lbm_amd.models.vae import AutoencoderKL
+    with torch.device("meta"):
+        for build in (build_relight_model, build_filllight_model):
+            with pytest.raises(FileNotFoundError, match="allow_random_init"):
+                build()
+        with pytest.raises(FileNotFoundError, match="allow_random_init"):
+            _get_model_from_config()
+        with pytest.raises(FileNotFoundError, match="allow_random_init"):
+            AutoencoderKL.from_pretrained("stabilityai/sdxl-vae")
+        with pytest.raises(ValueError, match="known backbone"):
+            AutoencoderKL.from_pretrained("someone/unknown-model", allow_random_init=True)
+        with pytest.raises(FileNotFoundError, match="allow_random_init"):
+            build_filllight_refine_model(backbone_signature="someone/unknown-model")
+    # the refine model has nothing to download but the scheduler config, which known backbone names imply
+    assert FlowMatchEulerDiscreteScheduler.from_pretrained("stable-diffusion-v1-5/stable-diffusion-v1-5",
+                                                           subfolder="scheduler").config.num_train_timesteps == 1000
+    with pytest.raises(FileNotFoundError):
+        FlowMatchEulerDiscreteScheduler.from_pretrained("someone/unknown-model", subfolder="scheduler")
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text('{"num_train_timesteps": 500, "shift": 2.0}')
+    s = FlowMatchEulerDiscreteScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    assert s.config.num_train_timesteps == 500 and s.config.shift == 2.0
+
+
+def test_resume_checkpoint_resolution(tmp_path):
+    """explicit path -> last.ckpt -> newest *.ckpt (examples/training/train_base.py:27-53)"""
+    import os
+    from lbm_amd.trainer import checkpoint_name, resolve_resume_checkpoint, resolve_task_dir
+    task = resolve_task_dir(str(tmp_path), "relight")
+    assert task.is_dir() and task.name == "relight"
+    assert resolve_resume_checkpoint(task, False, "whatever") is None
+    assert resolve_resume_checkpoint(task, True) is None
+    old, new = task / checkpoint_name(0, 100), task / checkpoint_name(1, 200)
+    old.write_bytes(b"a")
+    new.write_bytes(b"b")
+    os.utime(old, (1000, 1000))
+    os.utime(new, (2000, 2000))
+    assert new.name == "epoch=1-step=200.ckpt"
+    assert resolve_resume_checkpoint(task, True) == str(new)
+    assert resolve_resume_checkpoint(task, True, str(old)) == str(old)
+    assert resolve_resume_checkpoint(task, True, str(task / "missing.ckpt")) == str(new)     # warns, falls through
+    (task / "last.ckpt").write_bytes(b"c")
+    os.utime(task / "last.ckpt", (500, 500))
+    assert resolve_resume_checkpoint(task, True) == str(task / "last.ckpt")
 
 
 def test_lighting_embedder_shapes_and_rng_alignment():

@@ -185,7 +185,7 @@ def test_refine_unet_gradients_and_lpips_training_step(cuda):
         den += float(b.pow(2).sum())
     assert (num / den) ** 0.5 < 6e-2
 
-    model = build_filllight_refine_model(backbone_signature="offline", block_out_channels=[64, 64, 128], pixel_loss_type="lpips",
+    model = build_filllight_refine_model(backbone_signature="offline", allow_random_init=True, block_out_channels=[64, 64, 128], pixel_loss_type="lpips",
                                          pixel_loss_weight=1.0, bridge_noise_sigma=0.005)
     _randomise(model.lpips_loss)
     model = model.to(BF).to(cuda)

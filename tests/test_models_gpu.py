@@ -240,7 +240,7 @@ def test_training_forward_loss(small_unet, cuda):
                               lambda s, t: dr.unet_forward(usd, SMALL_UNET, s, t), 0.005)
     with torch.no_grad():
         out = model({"source_image": zs.to(cuda), "target_image": z.to(cuda)}, bridge_eps=eps.to(cuda), timesteps=ts)
-    assert rel_l2(out["noisy_sample"], ref["noisy_sample"]) < 4e-3      # interpolant of bf16 latents, f32 output
+    assert rel_l2(out["noisy_sample"], ref["noisy_sample"]) < 1e-5      # bf16-representable latents, f32 arithmetic and output
     assert torch.equal(out["noisy_sample"][1].cpu(), zs[1].float())       # t == 1000 -> exact source latent
     assert abs(float(out["loss"]) - float(ref["loss"])) / float(ref["loss"]) < 1e-2
     assert rel_l2(out["predicted_hr"], ref["predicted_hr"]) < 1e-2
@@ -346,7 +346,7 @@ def test_unet2d_refine_matches_oracle(cuda):
 
 def test_refine_model_builder_and_sampling(cuda):
     from lbm_amd.inference.relight import build_filllight_refine_model
-    model = build_filllight_refine_model(backbone_signature="offline", block_out_channels=[64, 64, 128], pixel_loss_weight=0.0,
+    model = build_filllight_refine_model(backbone_signature="offline", allow_random_init=True, block_out_channels=[64, 64, 128], pixel_loss_weight=0.0,
                                          bridge_noise_sigma=0.005).to(cuda)
     n = sum(p.numel() for p in model.denoiser.parameters())
     assert n > 0 and model.vae is None

@@ -80,6 +80,7 @@ def test_lbm_model_state_dict_prefixes():
 
 def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "lbmk.h")).read()
+    hdr = re.sub(r"#ifdef LBMK_DIAG.*?#endif", "", hdr, flags=re.S)      # diagnostic builds only, absent from the product
     declared = set(re.findall(r"\b(lbmk_[a-z0-9_]+)\s*\(", hdr))
     declared.discard("lbmk_igemm_desc")
     lib = ctypes.CDLL(os.path.join(ROOT, "lbm_amd", "lib", "liblbmk.so"))
@@ -89,6 +90,7 @@ def test_c_abi_exports_every_declared_symbol():
     from lbm_amd import _C
     assert set(_C.SIGNATURES) == declared
     assert _C.lib.lbmk_version() >= 1
+    assert not hasattr(lib, "lbmk_debug_igemm_times")      # the synchronising diagnostic is not in the product build
 
 
 def test_igemm_desc_layout_matches_header(tmp_path):
