@@ -356,6 +356,70 @@ def test_refine_model_builder_and_sampling(cuda):
     assert out.shape == (1, 3, 64, 64) and torch.isfinite(out.float()).all()
 
 
+@pytest.mark.slow_oracle
+def test_get_model_evaluate_end_to_end(cuda, tmp_path):
+    """BASELINE config 1 through the reference's own entry points (src/lbm/inference/utils.py:21-85,
+    src/lbm/inference/inference.py:27-70): a checkpoint directory (yaml + safetensors of the seeded full-size model)
+    -> get_model -> evaluate(PIL 512x512, 1 step), against the fp32 oracle on the same pixels and posterior noise.
+    evaluate() snaps the image to the closest aspect bucket, so a square input is processed at 1024x1024."""
+    import PIL.Image
+    import yaml
+    from safetensors.torch import save_file
+    import bench
+    from lbm_amd.inference import evaluate, get_model
+    from lbm_amd.inference.inference import _to_tensor, closest_bucket
+    from lbm_amd.inference.utils import sdxl_style_unet_kwargs
+    from oracle import bridge_ref as br
+    from oracle import diffusers_ref as dr
+    src = bench.build_model(cuda, 1024)
+    sd = {k: v.detach().cpu().contiguous() for k, v in src.state_dict().items()}
+    del src
+    torch.cuda.empty_cache()
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    (ckpt / "config.yaml").write_text(yaml.safe_dump(dict(
+        backbone_signature="stabilityai/stable-diffusion-xl-base-1.0", vae_num_channels=4, unet_input_channels=4,
+        timestep_sampling="custom_timesteps", selected_timesteps=[250, 500, 750, 1000], prob=[0.25, 0.25, 0.25, 0.25],
+        conditioning_images_keys=[], conditioning_masks_keys=[], source_key="source_image",
+        target_key="source_image_paste", bridge_noise_sigma=0.005)))
+    save_file(sd, str(ckpt / "model.safetensors"))
+    model = get_model(str(ckpt), torch_dtype=BF, device="cuda")
+    assert not model.training and model.vae.tiling_size == (128, 128) and model.bridge_noise_sigma == 0.005
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+    rng = np.random.default_rng(5)
+    pil = PIL.Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)).resize((64, 64)).resize((512, 512))
+    assert closest_bucket(pil) == (1024, 1024)
+    eps = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(6)).to(BF)
+    seen = {}
+    vae_encode = model.vae.encode
+
+    def encode_with_eps(x, *a, **k):
+        seen["z"] = vae_encode(x, *a, eps=eps.to(x.device), **k)
+        return seen["z"]
+
+    model.vae.encode = encode_with_eps
+    out = evaluate(model, pil, num_sampling_steps=1)
+    assert isinstance(out, PIL.Image.Image) and out.size == (1024, 1024)
+    # oracle: same pre-processing (bucket resize, *2-1, bf16 input), fp32 arithmetic
+    x = (_to_tensor(pil.resize((1024, 1024))).unsqueeze(0) * 2 - 1).to(BF).float()
+    usd = {k[len("denoiser."):]: v.float() for k, v in sd.items() if k.startswith("denoiser.")}
+    vsd = {k[len("vae.vae_model."):]: v.float() for k, v in sd.items() if k.startswith("vae.vae_model.")}
+    cfg = sdxl_style_unet_kwargs()
+    with torch.no_grad():
+        z_ref = dr.posterior_sample(dr.vae_encode_moments(vsd, x), eps.float()) * 0.13025
+        lat_ref = br.sample(z_ref, lambda s_, t: dr.unet_forward(usd, cfg, s_, t), 1, [], 0.005)
+        img_ref = dr.vae_decode(vsd, lat_ref / 0.13025).clamp(-1, 1)
+    ref8 = ((img_ref[0] + 1) / 2).mul(255).byte().permute(1, 2, 0).numpy()
+    got8 = np.asarray(out)
+    mse = float(((got8.astype(np.float64) - ref8.astype(np.float64)) ** 2).mean()) / 255.0 ** 2
+    psnr = 10 * math.log10(1.0 / max(mse, 1e-12))
+    zerr = rel_l2(seen["z"], z_ref)
+    print(f"get_model/evaluate 1024x1024 (bucket of a 512x512 input): encode rel-L2 {zerr:.4f}, image PSNR {psnr:.1f} dB")
+    assert zerr < 1e-2
+    assert psnr >= 40.0
+
+
 def test_full_size_pipeline_is_batch_consistent(cuda):
     """the headline workload's size (1024x1024, the 2.43 B-parameter UNet, SD VAE): an image gives the same output
     alone and as a member of a batch.  Tile shapes (hence which workgroup computes what) change with the batch size;
