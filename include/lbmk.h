@@ -77,6 +77,9 @@ typedef struct lbmk_igemm_desc {
                            index advancing a / w / out by sa2 / sw2 / so2 (attention heads inside images:
                            outer stride = one image, inner stride = head_dim columns); no residual         */
   int64_t sa2, sw2, so2;
+  int32_t in_f32;       /* fp32 mode: a, w, rowvec, residual and out are f32 (out_f32 must be 1) and the products run on
+                           v_mfma_f32_32x32x2_f32 (exact f32).  Any M / N; Cin, Kp, a_cs, a_coff multiples of 4; any
+                           KH x KW; k_order 0; LBMK_ACT_NONE / SILU / RELU; no gn_partial; tile is ignored            */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
@@ -337,6 +340,36 @@ int lbmk_lpips_head(const void* f0, const void* f1, const float* w, const uint8_
 /* df0 = gradient of (gout[b] / HW) * that sum with respect to f0 */
 int lbmk_lpips_head_bwd(const void* f0, const void* f1, const float* w, const uint8_t* keep, const float* gout,
                         void* df0, int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------
+ * fp32 mode: the model held and evaluated in f32 (get_model(..., torch_dtype=torch.float32),
+ * src/lbm/inference/utils.py:21-26, 81-82 — the reference's CPU-runnable configuration).  Same operators as above
+ * on f32 channels-last activations; statistics in f64, library exp / erf / sin / cos.  lbmk_igemm takes f32
+ * operands through lbmk_igemm_desc.in_f32.  Attention runs unfused: lbmk_igemm (scores, alpha = scale) ->
+ * lbmk_softmax_rows_f32 -> lbmk_igemm (probabilities x V^T).
+ * ---------------------------------------------------------------------- */
+int64_t lbmk_groupnorm_f32_scratch_floats(int B, int G);
+int lbmk_groupnorm_f32(const void* x, void* y, const float* gamma, const float* beta, float* scratch,
+                       int B, int HW, int C, int G, float eps, int silu, void* stream);     /* C % 4 == 0 */
+int lbmk_layernorm_f32(const void* x, void* y, const float* gamma, const float* beta,
+                       int rows, int C, float eps, void* stream);                            /* C <= 2048 */
+int lbmk_softmax_rows_f32(const float* s, float* p, int64_t rows, int cols, int64_t ld_in, int64_t ld_out, void* stream);
+/* GEGLU after the projection: y[r][c] = h[r][c] * gelu_erf(h[r][F + c]), h [rows][2F] (the value half comes first) */
+int lbmk_geglu_f32(const float* h, float* y, int64_t rows, int F, void* stream);
+/* NCHW (bf16 / f32, in_dtype 0 / 1) -> NHWC f32, channels zero-padded to Cp (multiple of 4) */
+int lbmk_nchw_to_nhwc_f32(const void* x, float* y, int B, int C, int H, int W, int Cp, int in_dtype, void* stream);
+/* NHWC f32 (channel stride Cs) -> NCHW bf16 / f32 (out_dtype 0 / 1) */
+int lbmk_nhwc_to_nchw_f32(const float* x, void* y, int B, int C, int H, int W, int Cs, int out_dtype, void* stream);
+int lbmk_copy_channels_f32(const float* src, float* dst, int64_t pixels, int C, int src_cs, int src_off,
+                           int dst_cs, int dst_off, void* stream);                           /* multiples of 4 */
+int lbmk_posterior_sample_f32(const float* moments, const float* eps, float* z, int B, int Cz, int HW, int ms,
+                              float shift, float scale, void* stream);
+int lbmk_timestep_embedding_f32(const float* t, float* out, int B, int dim, void* stream);
+int lbmk_silu_f32(const float* x, float* y, int64_t n, void* stream);
+int lbmk_scale_shift_f32(const float* x, float* y, int64_t n, float a, float b, void* stream);
+int lbmk_tile_accumulate_f32(const float* tile, float* acc, float* wsum, const float* wy, const float* wx,
+                             int B, int C, int Cs, int th_full, int tw_full, int th, int tw,
+                             int H, int W, int y0, int x0, void* stream);
 
 #ifdef __cplusplus
 }

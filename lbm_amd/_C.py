@@ -47,6 +47,7 @@ class IgemmDesc(C.Structure):
         ("tile", i32), ("k_order", i32),
         ("gn_partial", vp), ("gn_groups", i32),
         ("batch_inner", i32), ("sa2", i64), ("sw2", i64), ("so2", i64),
+        ("in_f32", i32),
     ]
 
 
@@ -108,6 +109,20 @@ SIGNATURES = {
     "lbmk_latent_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp]),
     "lbmk_pixel_loss": (i32, [vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
     "lbmk_pixel_loss_bwd": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),
+    "lbmk_groupnorm_f32_scratch_floats": (i64, [i32, i32]),
+    "lbmk_groupnorm_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "lbmk_layernorm_f32": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "lbmk_softmax_rows_f32": (i32, [vp, vp, i64, i32, i64, i64, vp]),
+    "lbmk_geglu_f32": (i32, [vp, vp, i64, i32, vp]),
+    "lbmk_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "lbmk_nhwc_to_nchw_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "lbmk_copy_channels_f32": (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp]),
+    "lbmk_posterior_sample_f32": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
+    "lbmk_timestep_embedding_f32": (i32, [vp, vp, i32, i32, vp]),
+    "lbmk_silu_f32": (i32, [vp, vp, i64, vp]),
+    "lbmk_scale_shift_f32": (i32, [vp, vp, i64, f32, f32, vp]),
+    "lbmk_tile_accumulate_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                       i32, i32, vp]),
     "lbmk_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
 }
 

@@ -670,8 +670,11 @@ extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
   return kNumTiles;
 }
 
+int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream);     // fp32.hip
+
 extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE(dp != nullptr, "igemm: null descriptor");
+  if (dp->in_f32) return lbmk_igemm_f32_launch(dp, stream);      // fp32 mode: f32 operands on the f32-input MFMA
   lbmk_igemm_desc d = *dp;
   LBMK_REQUIRE(d.a && d.w && d.out, "igemm: null operand");
   LBMK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "igemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);

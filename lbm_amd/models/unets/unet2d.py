@@ -80,7 +80,7 @@ class UNet2DModel(nn.Module, _Cached):
         t = t.to(device=device, dtype=torch.float32).reshape(-1)
         if t.numel() == 1:
             t = t.expand(B)
-        t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in)
+        t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in, dtype=self.conv_in.weight.dtype if self.conv_in.weight.dtype == torch.float32 else torch.bfloat16)
         if training(self.time_embedding.linear_1.weight):
             from ...autograd import SiluFn
             e = SiluFn.apply(self.time_embedding.linear_2(SiluFn.apply(self.time_embedding.linear_1(t_emb))))
@@ -106,7 +106,7 @@ class UNet2DModel(nn.Module, _Cached):
             from ...autograd import NchwToNhwcFn
             x = NchwToNhwcFn.apply(sample)
         else:
-            x = ops.nchw_to_nhwc(sample)
+            x = ops.nchw_to_nhwc(sample, dtype=torch.float32 if self.conv_in.weight.dtype == torch.float32 else torch.bfloat16)
         h = self.conv_in(x)
         skips = [h]
         for blk in self.down_blocks:

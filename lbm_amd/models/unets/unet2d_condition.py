@@ -112,7 +112,7 @@ class Attention(nn.Module, _Cached):
         """xn: normalised tokens [B, N, C]; ctx None => self-attention over xn (the reference passes
         encoder_hidden_states=None with cross_attention_dim == C, so attn2 is a self-attention too);
         residual: tensor added to the output projection in the GEMM epilogue."""
-        if self.dim_head not in (40, 64, 80, 160):
+        if self.dim_head not in (40, 64, 80, 160) and xn.dtype != torch.float32:
             raise NotImplementedError(f"flash attention kernels cover head_dim 40/64/80/160 (got {self.dim_head})")
         C = self.inner_dim
         if training(xn, self.to_q.weight):
@@ -136,12 +136,12 @@ class Attention(nn.Module, _Cached):
         else:
             # a handful of context tokens (lighting parameters): K / V come from ctx, keys past the
             # token count are masked in the kernel; V^T is padded to a multiple of 8 keys with zeros
-            ctx = ctx.to(torch.bfloat16).contiguous()
+            ctx = ctx.to(xn.dtype).contiguous()
             M = ctx.shape[1]
             q = self.to_q(xn)
             k = self.to_k(ctx)
             v = self.to_v(ctx)                              # [B, M, C]
-            vt = torch.zeros(ctx.shape[0], C, (M + 7) // 8 * 8, dtype=torch.bfloat16, device=ctx.device)
+            vt = torch.zeros(ctx.shape[0], C, (M + 7) // 8 * 8, dtype=xn.dtype, device=ctx.device)
             vt[:, :, :M] = v.transpose(1, 2)
             o = ops.flash_attn(q, k, vt, self.heads, self.dim_head)
         return self.to_out[0](o, residual=residual)
@@ -332,6 +332,11 @@ class UNet2DConditionModel(nn.Module, _Cached):
         self.conv_act = nn.SiLU()
         self.conv_out = HipConv2d(chans[0], out_channels, 3, padding=1)
 
+    @property
+    def compute_dtype(self) -> torch.dtype:
+        """activation dtype: f32 when the model is held in f32 (fp32 mode), bf16 otherwise"""
+        return torch.float32 if self.conv_in.weight.dtype == torch.float32 else torch.bfloat16
+
     # ---- time embedding: every resnet's projection in one GEMM -----------------------------
     def _resnets(self) -> List[ResnetBlock2D]:
         rs = []
@@ -346,7 +351,7 @@ class UNet2DConditionModel(nn.Module, _Cached):
         t = t.to(device=device, dtype=torch.float32).reshape(-1)
         if t.numel() == 1:
             t = t.expand(B)
-        t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in)
+        t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in, dtype=self.compute_dtype)
         if training(self.time_embedding.linear_1.weight):
             from ...autograd import SiluFn
             e = SiluFn.apply(self.time_embedding.linear_2(SiluFn.apply(self.time_embedding.linear_1(t_emb))))
@@ -376,7 +381,7 @@ class UNet2DConditionModel(nn.Module, _Cached):
             from ...autograd import NchwToNhwcFn
             x = NchwToNhwcFn.apply(sample)
         else:
-            x = ops.nchw_to_nhwc(sample)
+            x = ops.nchw_to_nhwc(sample, dtype=self.compute_dtype)
         ctx = encoder_hidden_states
         h = self.conv_in(x)
         skips = [h]

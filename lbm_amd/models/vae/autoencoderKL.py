@@ -65,13 +65,14 @@ class AutoencoderKLDiffusers(BaseModel):
                                     float(self.shift_factor))
             img = self.vae_model.decode_nhwc(NchwToNhwcFn.apply(zs))
             return NhwcToNchwFn.apply(img, self.vae_model.config.out_channels, z.dtype)
+        adt = self.vae_model.compute_dtype
         zc = z.contiguous()
-        if zc.dtype != torch.bfloat16:
-            zc = zc.to(torch.bfloat16)
+        if zc.dtype != adt:
+            zc = zc.to(adt)
         zs = ops.scale_shift(zc, 1.0 / float(self.vae_model.config.scaling_factor), float(self.shift_factor))
         use_tiling = z.shape[2] > self.tiling_size[0] or z.shape[3] > self.tiling_size[1]
         if not use_tiling:
-            img = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(zs))
+            img = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(zs, dtype=adt))
             return ops.nhwc_to_nchw(img, self.vae_model.config.out_channels, out_dtype=z.dtype)
         return self._tiled_decode(zs)
 
@@ -96,7 +97,7 @@ class AutoencoderKLDiffusers(BaseModel):
                 t = zs[:, :, y0:y0 + th, x0:x0 + tw]
                 t = torch.nn.functional.pad(t, (0, tw - t.shape[3], 0, th - t.shape[2]))   # zero pad to the tile size
                 tiles.append(t)
-            dec = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(torch.cat(tiles, 0)))   # [len*B, th*f, tw*f, 8]
+            dec = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(torch.cat(tiles, 0), dtype=self.vae_model.compute_dtype))   # [len*B, th*f, tw*f, 8]
             for k, (y0, x0) in enumerate(group):
                 hh, ww = min(th, H - y0) * f, min(tw, W - x0) * f
                 wy = torch.tensor(gaussian_weights_1d(hh, hh / 2), dtype=torch.float32, device=zs.device)

@@ -57,7 +57,7 @@ class VaeAttention(nn.Module, _Cached):
             from ...autograd import AttentionFn
             o = AttentionFn.apply(self.to_q(xn), self.to_k(xn), self.to_v(xn), self.heads, D, 1.0 / math.sqrt(D))
             return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
-        if D in FLASH_HEAD_DIMS:
+        if D in FLASH_HEAD_DIMS or xn.dtype == torch.float32:      # fp32 mode: the unfused f32 attention takes any D
             wv, bv = self._v_weight()
             o = ops.flash_attn(self.to_q(xn), self.to_k(xn), ops.gemm_nt(wv, xn, bias_m=bv), self.heads, D)
             return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
@@ -261,8 +261,13 @@ class AutoencoderKL(nn.Module):
         return cls(**known_vae_config(version))
 
     # ---- API as used by the reference wrapper (autoencoderKL.py:64,116,134) -----------------
+    @property
+    def compute_dtype(self) -> torch.dtype:
+        """activation dtype: f32 when the model is held in f32 (fp32 mode), bf16 otherwise"""
+        return torch.float32 if self.quant_conv.weight.dtype == torch.float32 else torch.bfloat16
+
     def encode(self, x: torch.Tensor) -> AutoencoderKLOutput:
-        xh = ops.nchw_to_nhwc(x)
+        xh = ops.nchw_to_nhwc(x, dtype=self.compute_dtype)
         h = self.encoder(xh)
         moments = self.quant_conv(h)
         return AutoencoderKLOutput(DiagonalGaussianDistribution(moments, self.config.latent_channels, x.dtype))
@@ -272,6 +277,6 @@ class AutoencoderKL(nn.Module):
         return self.decoder(self.post_quant_conv(z_nhwc))
 
     def decode(self, z: torch.Tensor) -> DecoderOutput:
-        zh = ops.nchw_to_nhwc(z)
+        zh = ops.nchw_to_nhwc(z, dtype=self.compute_dtype)
         img = self.decode_nhwc(zh)
         return DecoderOutput(ops.nhwc_to_nchw(img, self.config.out_channels, out_dtype=z.dtype))

@@ -40,6 +40,16 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype} (bf16 / f32 only)")
 
 
+def _act_f32(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """fp32 mode when both the activation and the weight operand are f32; bf16 otherwise (mixing is an error)"""
+    if x.dtype == torch.float32 and w.dtype == torch.float32:
+        return True
+    if x.dtype == bf16 and w.dtype == bf16:
+        return False
+    raise TypeError(f"activation {x.dtype} with weights {w.dtype}: a module runs in bf16 or in f32 (fp32 mode), "
+                    "cast the model with .to(dtype)")
+
+
 def ceil_to(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -72,6 +82,15 @@ def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pack
     n_p = ceil_to(N, 8)
     K = KH * KW * cin_p
     Kp = ceil_to(K, 64)
+    if weight.dtype == torch.float32:
+        # fp32 mode: f32 operand in tap-major K order (the f32 kernel takes any geometry)
+        w = torch.zeros(n_p, KH * KW, cin_p, dtype=torch.float32, device=weight.device)
+        w[:N, :, :Cin] = weight.detach().permute(0, 2, 3, 1).reshape(N, KH * KW, Cin)
+        b = None
+        if bias is not None:
+            b = torch.zeros(n_p, dtype=torch.float32, device=weight.device)
+            b[:N] = bias.detach().float()
+        return PackedWeight(w.reshape(n_p, K).contiguous(), b, n_p, K, K, cin_p, KH, KW, alg_nk=N * KH * KW * Cin)
     if weight.is_cuda and weight.dtype == bf16 and weight.is_contiguous():
         return _pack_conv_weight_dev(weight.detach(), bias, False)
     w = torch.zeros(N, KH * KW, cin_p, dtype=bf16, device=weight.device)
@@ -121,6 +140,13 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pa
     k8 = ceil_to(K, 8)
     b = None if bias is None else bias.detach().float().contiguous()
     w = weight.detach()
+    if w.dtype == torch.float32:
+        # fp32 mode: the f32 parameter itself when its rows are 16-byte multiples
+        if K == k8 and w.is_contiguous() and w.data_ptr() % 16 == 0:
+            return PackedWeight(w, b, N, k8, k8, k8, 1, 1, alg_nk=N * K)
+        packed = torch.zeros(N, k8, dtype=torch.float32, device=w.device)
+        packed[:, :K] = w
+        return PackedWeight(packed, b, N, k8, k8, k8, 1, 1, alg_nk=N * K)
     if K == k8 and w.dtype == bf16 and w.is_contiguous() and w.data_ptr() % 16 == 0:
         # already the kernel's layout: alias the parameter (the K tail of the last 64-deep tile is masked
         # by the kernel), so an optimizer step needs no re-pack
@@ -138,6 +164,11 @@ def pack_geglu_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pac
     epilogue holds a value and its gate."""
     N2, K = weight.shape
     F = N2 // 2
+    if weight.dtype == torch.float32:
+        # fp32 mode: plain [2F, K] projection; the gate is applied by its own kernel (lbmk_geglu_f32)
+        pw = pack_linear_weight(weight, bias)
+        pw.geglu = True
+        return pw
     assert F % 16 == 0
     idx = torch.arange(F, device=weight.device).reshape(F // 16, 16)
     order = torch.cat([idx, idx + F], dim=1).reshape(-1)
@@ -210,7 +241,8 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
     gn_groups > 0: the epilogue also writes GroupNorm partial sums for a consumer with that many groups
     (when the shape allows); they ride on the returned tensor and `groupnorm` picks them up."""
     _need_gpu(x, pw.w)
-    assert x.dtype == bf16 and x.dim() == 4 and x.is_contiguous()
+    f32 = _act_f32(x, pw.w)
+    assert x.dim() == 4 and x.is_contiguous()
     B, IH, IW, Cs = x.shape
     IHe, IWe = (2 * IH, 2 * IW) if up2 else (IH, IW)
     if out_hw is None:
@@ -218,13 +250,15 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
         OW = (IWe + 2 * pad[1] - pw.KW) // stride + 1
     else:
         OH, OW = out_hw
+    assert not (f32 and pw.geglu), "GEGLU projections are linear layers"
     n_out = pw.N // 2 if pw.geglu else pw.N
-    out = torch.empty(B, OH, OW, n_out, dtype=bf16, device=x.device)
+    out = torch.empty(B, OH, OW, n_out, dtype=x.dtype, device=x.device)
     d = IgemmDesc()
     d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), out.data_ptr()
     d.bias = _ptr(pw.bias)
     d.rowvec = _ptr(rowvec)
     d.residual = _ptr(residual)
+    d.in_f32 = 1 if f32 else 0
     d.M, d.N, d.K, d.Kp = B * OH * OW, pw.N, pw.K, pw.Kp
     d.Cin, d.a_cs, d.a_coff = pw.Cin, Cs, cin_off
     d.IH, d.IW, d.OH, d.OW = IH, IW, OH, OW
@@ -234,17 +268,17 @@ def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up
     d.ldr = residual.shape[-1] if residual is not None else 0
     d.rowvec_ld = rowvec.stride(0) if rowvec is not None else 0
     if residual is not None:
-        assert residual.dtype == bf16 and residual.is_contiguous() and residual.numel() == d.M * d.ldr
+        assert residual.dtype == x.dtype and residual.is_contiguous() and residual.numel() == d.M * d.ldr
     if rowvec is not None:
         # [B, N] rows, possibly a column window of a wider matrix
-        assert rowvec.dtype == bf16 and rowvec.dim() == 2 and rowvec.stride(1) == 1
+        assert rowvec.dtype == x.dtype and rowvec.dim() == 2 and rowvec.stride(1) == 1
         assert rowvec.shape == (B, pw.N)
     d.act = ACT_GEGLU if pw.geglu else act
-    d.out_f32, d.bias_per_m, d.alpha = 0, 0, 1.0
+    d.out_f32, d.bias_per_m, d.alpha = (1 if f32 else 0), 0, 1.0
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
     d.k_order = pw.k_order
-    partial = _attach_gn_partial(d, out, gn_groups) if gn_groups and n_out == pw.N else None
+    partial = _attach_gn_partial(d, out, gn_groups) if (gn_groups and n_out == pw.N and not f32) else None
     _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
     if partial is not None:
         out._lbmk_gn_partial = partial
@@ -266,7 +300,18 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
            out: Optional[torch.Tensor] = None, tile: int = -1) -> torch.Tensor:
     """x: bf16 [..., K] with contiguous rows (row stride = x.stride(-2)); returns [..., N]."""
     _need_gpu(x, pw.w)
-    assert x.dtype == bf16 and x.stride(-1) == 1
+    f32 = _act_f32(x, pw.w)
+    assert x.stride(-1) == 1
+    if f32 and pw.geglu:
+        # fp32 mode: projection to [.., 2F], then the gate as its own kernel
+        plain = PackedWeight(pw.w, pw.bias, pw.N, pw.K, pw.Kp, pw.Cin, 1, 1, alg_nk=pw.alg_nk)
+        h = linear(x, plain, tile=tile)
+        assert residual is None and rowvec is None and act == ACT_NONE
+        F = pw.N // 2
+        y = out if out is not None else torch.empty(*x.shape[:-1], F, dtype=torch.float32, device=x.device)
+        assert y.is_contiguous()
+        check(lib.lbmk_geglu_f32(h.data_ptr(), y.data_ptr(), h.numel() // pw.N, F, _stream()), "lbmk_geglu_f32")
+        return y
     lead = x.shape[:-1]
     M = 1
     for s in lead:
@@ -279,17 +324,20 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
         assert x.is_contiguous() or all(x.stride(i) == x.stride(i + 1) * x.shape[i + 1] for i in range(x.dim() - 2))
     n_out = pw.N // 2 if pw.geglu else pw.N
     if out is None:
-        out = torch.empty(*lead, n_out, dtype=bf16, device=x.device)
+        out = torch.empty(*lead, n_out, dtype=x.dtype, device=x.device)
+    assert not f32 or out.dtype == torch.float32
     d = IgemmDesc()
     d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), out.data_ptr()
     d.bias, d.rowvec, d.residual = _ptr(pw.bias), _ptr(rowvec), _ptr(residual)
+    d.in_f32 = 1 if f32 else 0
+    assert residual is None or residual.dtype == x.dtype
     d.M, d.N, d.K, d.Kp = M, pw.N, pw.K, pw.Kp
     d.Cin, d.a_cs, d.a_coff = pw.K, lda, 0
     if rowvec is not None:
         # rows of one image are consecutive: model them as a rows_per_image x 1 "image"
         assert rows_per_image > 0 and M % rows_per_image == 0
         d.IH, d.IW, d.OH, d.OW = rows_per_image, 1, rows_per_image, 1
-        assert rowvec.dtype == bf16 and rowvec.dim() == 2 and rowvec.stride(1) == 1
+        assert rowvec.dtype == x.dtype and rowvec.dim() == 2 and rowvec.stride(1) == 1
         d.rowvec_ld = rowvec.stride(0)
     else:
         d.IH = d.IW = d.OH = d.OW = 1
@@ -316,13 +364,19 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     bias_m: f32 [M] per output row; bias_n: f32 [N].
     ``out``: optional preallocated view of the result shape (unit column stride; other strides free)."""
     _need_gpu(a, b)
-    assert a.dtype == bf16 and b.dtype == bf16 and a.stride(-1) == 1 and b.stride(-1) == 1
+    f32 = _act_f32(a, b)
+    if f32:
+        out_dtype = torch.float32
+    assert a.stride(-1) == 1 and b.stride(-1) == 1
     nb = max(a.dim(), b.dim()) - 2
     assert nb in (0, 1, 2) and a.dim() in (2, nb + 2) and b.dim() in (2, nb + 2)
     lead = tuple((a if a.dim() == nb + 2 else b).shape[:nb])
     M, K = a.shape[-2], a.shape[-1]
     N = b.shape[-2]
-    assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0 and a.stride(-2) % 8 == 0
+    if f32:
+        assert b.shape[-1] == K and K % 4 == 0 and b.stride(-2) % 4 == 0 and a.stride(-2) % 4 == 0
+    else:
+        assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0 and a.stride(-2) % 8 == 0
     shape = lead + (M, N)
     if out is None:
         out = torch.empty(*shape, dtype=out_dtype, device=a.device)
@@ -336,6 +390,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     d.bias_per_m = 1 if bias_m is not None else 0
     d.rowvec = None
     d.residual = _ptr(residual)
+    d.in_f32 = 1 if f32 else 0
     d.M, d.N, d.K, d.Kp = M, N, K, b.stride(-2)
     d.Cin, d.a_cs, d.a_coff = K, a.stride(-2), 0
     d.IH = d.IW = d.OH = d.OW = 1
@@ -370,11 +425,17 @@ _gn_scratch = {}
 
 def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], groups: int,
               eps: float, silu: bool) -> torch.Tensor:
-    """x: bf16 [B, H, W, C] (or [B, HW, C]); gamma/beta f32 [C]."""
+    """x: bf16 (or f32: fp32 mode) [B, H, W, C] (or [B, HW, C]); gamma/beta f32 [C]."""
     _need_gpu(x)
-    assert x.dtype == bf16 and x.is_contiguous()
+    assert x.dtype in (bf16, torch.float32) and x.is_contiguous()
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    if x.dtype == torch.float32:
+        buf = torch.empty(lib.lbmk_groupnorm_f32_scratch_floats(B, groups), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.lbmk_groupnorm_f32(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), buf.data_ptr(), B, HW, Cc, groups,
+                                     eps, 1 if silu else 0, _stream()), "lbmk_groupnorm_f32")
+        return y
     fused = getattr(x, "_lbmk_gn_partial", None)
     if fused is not None and fused[1] == groups and fused[0].numel() == B * groups * fused[2] * 2:
         # the producing convolution already reduced this tensor: finalize + apply only
@@ -404,10 +465,14 @@ def groupnorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[tor
 def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
               eps: float = 1e-5) -> torch.Tensor:
     _need_gpu(x)
-    assert x.dtype == bf16 and x.is_contiguous()
+    assert x.dtype in (bf16, torch.float32) and x.is_contiguous()
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     y = torch.empty_like(x)
+    if x.dtype == torch.float32:
+        check(lib.lbmk_layernorm_f32(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()),
+              "lbmk_layernorm_f32")
+        return y
     _timed("layernorm", 4.0 * x.numel(), lambda: check(
         lib.lbmk_layernorm(x.data_ptr(), y.data_ptr(), _ptr(gamma), _ptr(beta), rows, Cc, eps, _stream()), "lbmk_layernorm"))
     return y
@@ -421,12 +486,15 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, h
     """q: [B, Nq, >=H*D] (last-dim view allowed), k: [B, Nk, >=H*D], vt: [B, H*D, Nk].
     ``return_lse``: also return the f32 [B, H, Nq] log2-sum-exp rows ``flash_attn_bwd`` consumes."""
     _need_gpu(q, k, vt)
-    assert q.dtype == bf16 and k.dtype == bf16 and vt.dtype == bf16
+    assert q.dtype == k.dtype == vt.dtype and q.dtype in (bf16, torch.float32)
     assert q.stride(-1) == 1 and k.stride(-1) == 1 and vt.stride(-1) == 1
     B, Nq = q.shape[0], q.shape[1]
     Nk = k.shape[1]
     if scale is None:
         scale = 1.0 / math.sqrt(head_dim)
+    if q.dtype == torch.float32:
+        assert not return_lse
+        return _attention_f32(q, k, vt, heads, head_dim, scale)
     o = torch.empty(B, Nq, heads * head_dim, dtype=bf16, device=q.device)
     lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device) if return_lse else None
     _timed("flash_attn", 4.0 * B * heads * Nq * Nk * head_dim, lambda: check(
@@ -435,6 +503,32 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, h
                                 q.stride(0), k.stride(0), vt.stride(0), o.stride(0), scale,
                                 lse.data_ptr() if return_lse else None, _stream()), "lbmk_flash_attn_fwd"))
     return (o, lse) if return_lse else o
+
+
+def _attention_f32(q, k, vt, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    """fp32 mode: softmax(q k^T * scale) v with the scores materialised — scores GEMM batched over (image, head),
+    f32 row softmax, probabilities x V^T — in chunks of images that keep the score buffer under 2 GiB.
+    Keys at or past k.shape[1] (zero columns padding V^T to a multiple of 4) get probability 0."""
+    B, Nq, Nk = q.shape[0], q.shape[1], k.shape[1]
+    H, D = heads, head_dim
+    C = H * D
+    nkp = vt.shape[2]
+    assert nkp >= Nk and nkp % 4 == 0 and vt.shape[1] == C
+    o = torch.empty(B, Nq, C, dtype=torch.float32, device=q.device)
+    nb = max(1, min(B, (2 << 30) // (H * Nq * nkp * 4)))
+    for b0 in range(0, B, nb):
+        b1 = min(B, b0 + nb)
+        n = b1 - b0
+        qh = q[b0:b1, :, :C].unflatten(2, (H, D)).permute(0, 2, 1, 3)            # [n, H, Nq, D] views
+        kh = k[b0:b1, :, :C].unflatten(2, (H, D)).permute(0, 2, 1, 3)            # [n, H, Nk, D]
+        s = torch.zeros(n, H, Nq, nkp, dtype=torch.float32, device=q.device) if nkp != Nk else \
+            torch.empty(n, H, Nq, nkp, dtype=torch.float32, device=q.device)
+        gemm_nt(qh, kh, alpha=scale, out=s[..., :Nk] if nkp != Nk else s)
+        check(lib.lbmk_softmax_rows_f32(s.data_ptr(), s.data_ptr(), n * H * Nq, Nk, nkp, nkp, _stream()), "lbmk_softmax_rows_f32")
+        vh = vt[b0:b1].unflatten(1, (H, D))                                      # [n, H, D, nkp]
+        gemm_nt(s, vh, out=o[b0:b1].unflatten(2, (H, D)).permute(0, 2, 1, 3))
+        del s
+    return o
 
 
 FLASH_BWD_HEAD_DIMS = (40, 64, 80, 160)
@@ -480,12 +574,15 @@ def flash_attn_bwd(q, k, v, o, do, lse, heads: int, head_dim: int, scale: float,
     return dq, dk, dv
 
 
-def softmax_rows(s: torch.Tensor) -> torch.Tensor:
-    """f32 [..., cols] -> bf16 probabilities."""
+def softmax_rows(s: torch.Tensor, out_dtype=bf16) -> torch.Tensor:
+    """f32 [..., cols] -> bf16 probabilities (``out_dtype=torch.float32``: fp32 mode, in place)."""
     _need_gpu(s)
     assert s.dtype == torch.float32 and s.is_contiguous()
     cols = s.shape[-1]
     rows = s.numel() // cols
+    if out_dtype == torch.float32:
+        check(lib.lbmk_softmax_rows_f32(s.data_ptr(), s.data_ptr(), rows, cols, cols, cols, _stream()), "lbmk_softmax_rows_f32")
+        return s
     p = torch.empty(s.shape, dtype=bf16, device=s.device)
     _timed("softmax_rows", 6.0 * s.numel(), lambda: check(
         lib.lbmk_softmax_rows(s.data_ptr(), p.data_ptr(), rows, cols, cols, cols, _stream()), "lbmk_softmax_rows"))
@@ -551,11 +648,16 @@ def axpy_rows(x, y, a):
 # --------------------------------------------------------------------------------------
 # layout / glue
 # --------------------------------------------------------------------------------------
-def nchw_to_nhwc(x: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
+def nchw_to_nhwc(x: torch.Tensor, cp: Optional[int] = None, dtype=bf16) -> torch.Tensor:
+    """NCHW (bf16 / f32) -> channels-last ``dtype`` (bf16, or f32 in fp32 mode), channels zero-padded to ``cp``"""
     _need_gpu(x)
     x = x.contiguous()
     B, Cc, H, W = x.shape
     cp = ceil_to(Cc, 8) if cp is None else cp
+    if dtype == torch.float32:
+        y = torch.empty(B, H, W, cp, dtype=torch.float32, device=x.device)
+        check(lib.lbmk_nchw_to_nhwc_f32(x.data_ptr(), y.data_ptr(), B, Cc, H, W, cp, _dt(x), _stream()), "lbmk_nchw_to_nhwc_f32")
+        return y
     y = torch.empty(B, H, W, cp, dtype=bf16, device=x.device)
     check(lib.lbmk_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cc, H, W, cp, _dt(x), _stream()), "lbmk_nchw_to_nhwc")
     return y
@@ -563,21 +665,29 @@ def nchw_to_nhwc(x: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
 
 def nhwc_to_nchw(x: torch.Tensor, channels: int, out_dtype=bf16) -> torch.Tensor:
     _need_gpu(x)
-    assert x.dtype == bf16 and x.is_contiguous()
+    assert x.dtype in (bf16, torch.float32) and x.is_contiguous()
     B, H, W, Cs = x.shape
     y = torch.empty(B, channels, H, W, dtype=out_dtype, device=x.device)
+    if x.dtype == torch.float32:
+        check(lib.lbmk_nhwc_to_nchw_f32(x.data_ptr(), y.data_ptr(), B, channels, H, W, Cs, _dt(y), _stream()),
+              "lbmk_nhwc_to_nchw_f32")
+        return y
     check(lib.lbmk_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), B, channels, H, W, Cs, _dt(y), _stream()),
           "lbmk_nhwc_to_nchw")
     return y
 
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """cat([a, b], channel axis) for channels-last bf16 tensors."""
+    """cat([a, b], channel axis) for channels-last tensors (bf16, or f32 in fp32 mode)."""
     _need_gpu(a, b)
-    assert a.shape[:-1] == b.shape[:-1] and a.is_contiguous() and b.is_contiguous()
+    assert a.shape[:-1] == b.shape[:-1] and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
     Ca, Cb = a.shape[-1], b.shape[-1]
-    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=bf16, device=a.device)
+    out = torch.empty(*a.shape[:-1], Ca + Cb, dtype=a.dtype, device=a.device)
     pixels = a.numel() // Ca
+    if a.dtype == torch.float32:
+        check(lib.lbmk_copy_channels_f32(a.data_ptr(), out.data_ptr(), pixels, Ca, Ca, 0, Ca + Cb, 0, _stream()), "copy_channels_f32")
+        check(lib.lbmk_copy_channels_f32(b.data_ptr(), out.data_ptr(), pixels, Cb, Cb, 0, Ca + Cb, Ca, _stream()), "copy_channels_f32")
+        return out
     check(lib.lbmk_copy_channels(a.data_ptr(), out.data_ptr(), pixels, Ca, Ca, 0, Ca + Cb, 0, _stream()), "copy_channels")
     check(lib.lbmk_copy_channels(b.data_ptr(), out.data_ptr(), pixels, Cb, Cb, 0, Ca + Cb, Ca, _stream()), "copy_channels")
     return out
@@ -586,18 +696,28 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def posterior_sample(moments: torch.Tensor, eps: torch.Tensor, cz: int, shift: float, scale: float) -> torch.Tensor:
     """moments: bf16 NHWC [B, H, W, ms]; eps: NCHW [B, cz, H, W] (bf16 / f32) -> z NCHW, eps.dtype."""
     _need_gpu(moments, eps)
-    assert moments.dtype == bf16 and moments.is_contiguous() and eps.is_contiguous()
+    assert moments.dtype in (bf16, torch.float32) and moments.is_contiguous() and eps.is_contiguous()
     B, H, W, ms = moments.shape
     assert eps.shape == (B, cz, H, W)
+    if moments.dtype == torch.float32:
+        eps = eps.float()
+        z = torch.empty_like(eps)
+        check(lib.lbmk_posterior_sample_f32(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), B, cz, H * W, ms, float(shift),
+                                            float(scale), _stream()), "lbmk_posterior_sample_f32")
+        return z
     z = torch.empty_like(eps)
     check(lib.lbmk_posterior_sample(moments.data_ptr(), eps.data_ptr(), z.data_ptr(), B, cz, H * W, ms,
                                     float(shift), float(scale), _dt(eps), _stream()), "lbmk_posterior_sample")
     return z
 
 
-def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+def timestep_embedding(t: torch.Tensor, dim: int, dtype=bf16) -> torch.Tensor:
     _need_gpu(t)
     t = t.reshape(-1).float().contiguous()
+    if dtype == torch.float32:
+        out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+        check(lib.lbmk_timestep_embedding_f32(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()), "timestep_embedding_f32")
+        return out
     out = torch.empty(t.shape[0], dim, dtype=bf16, device=t.device)
     check(lib.lbmk_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream()), "timestep_embedding")
     return out
@@ -605,16 +725,22 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
 
 def silu(x: torch.Tensor) -> torch.Tensor:
     _need_gpu(x)
-    assert x.dtype == bf16 and x.is_contiguous()
+    assert x.dtype in (bf16, torch.float32) and x.is_contiguous()
     y = torch.empty_like(x)
+    if x.dtype == torch.float32:
+        check(lib.lbmk_silu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lbmk_silu_f32")
+        return y
     check(lib.lbmk_silu(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "lbmk_silu")
     return y
 
 
 def scale_shift(x: torch.Tensor, a: float, b: float) -> torch.Tensor:
     _need_gpu(x)
-    assert x.dtype == bf16 and x.is_contiguous()
+    assert x.dtype in (bf16, torch.float32) and x.is_contiguous()
     y = torch.empty_like(x)
+    if x.dtype == torch.float32:
+        check(lib.lbmk_scale_shift_f32(x.data_ptr(), y.data_ptr(), x.numel(), float(a), float(b), _stream()), "scale_shift_f32")
+        return y
     check(lib.lbmk_scale_shift(x.data_ptr(), y.data_ptr(), x.numel(), float(a), float(b), _stream()), "scale_shift")
     return y
 
@@ -624,6 +750,10 @@ def tile_accumulate(tile, acc, wsum, wy, wx, th, tw, y0, x0, channels):
     B, thf, twf, Cs = tile.shape
     _, Cc, H, W = acc.shape
     assert Cc == channels and acc.dtype == torch.float32 and wsum.shape == (H, W)
+    if tile.dtype == torch.float32:
+        check(lib.lbmk_tile_accumulate_f32(tile.data_ptr(), acc.data_ptr(), wsum.data_ptr(), wy.data_ptr(), wx.data_ptr(),
+                                           B, Cc, Cs, thf, twf, th, tw, H, W, y0, x0, _stream()), "tile_accumulate_f32")
+        return
     check(lib.lbmk_tile_accumulate(tile.data_ptr(), acc.data_ptr(), wsum.data_ptr(), wy.data_ptr(), wx.data_ptr(),
                                    B, Cc, Cs, thf, twf, th, tw, H, W, y0, x0, _stream()), "tile_accumulate")
 

@@ -1,0 +1,148 @@
+"""fp32 mode (model held in f32: get_model(..., torch_dtype=torch.float32)) against the fp32 CPU oracle.
+Tolerance: latent relative L2 <= 1e-5 (the north-star's fp32 bound); kernels 2e-6."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_models_gpu import SD15_STYLE, SMALL_UNET, f32_state, psnr01, rel_l2
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from lbm_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,up2,H", [(64, 96, 3, 1, False, 12), (8, 40, 3, 1, False, 9), (72, 8, 3, 2, False, 10),
+                                                     (128, 136, 1, 1, False, 7), (64, 64, 3, 1, True, 6)])
+def test_conv2d_f32(ops, cuda, cin, cout, k, stride, up2, H):
+    g = torch.Generator().manual_seed(cin + cout)
+    B, W = 2, H + 3
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (k * k * cin) ** -0.5
+    b = torch.randn(cout, generator=g)
+    pw = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
+    xi = x.permute(0, 3, 1, 2).double()
+    if up2:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xi, w.double(), b.double(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    rv = torch.randn(B, pw.N, generator=g)
+    res = torch.randn(*ref.shape[:3], pw.N, generator=g)
+    y = ops.conv2d(x.to(cuda), pw, stride=stride, pad=(k // 2, k // 2), up2=up2, rowvec=rv.to(cuda), residual=res.to(cuda),
+                   act=ops.ACT_SILU)
+    assert y.dtype == F32
+    full = torch.zeros_like(res, dtype=torch.float64)
+    full[..., :cout] = ref
+    full = F.silu(full + rv[:, None, None, :].double() + res.double())
+    assert rel_l2(y, full) < 2e-6
+
+
+def test_linear_geglu_gemm_f32(ops, cuda):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 50, 72, generator=g)
+    w = torch.randn(2 * 48, 72, generator=g) * 72 ** -0.5
+    b = torch.randn(2 * 48, generator=g)
+    y = ops.linear(x.to(cuda), ops.pack_geglu_weight(w.to(cuda), b.to(cuda)))
+    h = x.double() @ w.double().t() + b.double()
+    ref = h[..., :48] * F.gelu(h[..., 48:])
+    assert y.shape == (3, 50, 48) and rel_l2(y, ref) < 2e-6
+    a = torch.randn(2, 3, 37, 40, generator=g)
+    bb = torch.randn(2, 3, 21, 40, generator=g)
+    out = ops.gemm_nt(a.to(cuda), bb.to(cuda), alpha=0.3)
+    assert rel_l2(out, 0.3 * a.double() @ bb.double().transpose(-1, -2)) < 2e-6
+
+
+def test_norms_softmax_f32(ops, cuda):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 100, 320, generator=g) * 3 + 1
+    ga, be = torch.randn(320, generator=g), torch.randn(320, generator=g)
+    y = ops.groupnorm(x.to(cuda), ga.to(cuda), be.to(cuda), 32, 1e-5, True)
+    ref = F.silu(F.group_norm(x.double().permute(0, 2, 1), 32, ga.double(), be.double(), 1e-5)).permute(0, 2, 1)
+    assert rel_l2(y, ref) < 2e-6
+    y = ops.layernorm(x.to(cuda), ga.to(cuda), be.to(cuda), 1e-5)
+    assert rel_l2(y, F.layer_norm(x.double(), (320,), ga.double(), be.double(), 1e-5)) < 2e-6
+    s = torch.randn(7, 300, generator=g) * 4
+    p = ops.softmax_rows(s.to(cuda).clone(), out_dtype=F32)
+    assert rel_l2(p, torch.softmax(s.double(), -1)) < 2e-6
+
+
+@pytest.mark.parametrize("H,D,Nq,Nk", [(2, 64, 100, 100), (8, 40, 64, 5)])
+def test_attention_f32(ops, cuda, H, D, Nq, Nk):
+    g = torch.Generator().manual_seed(3)
+    B, C = 2, H * D
+    q, k, v = torch.randn(B, Nq, C, generator=g), torch.randn(B, Nk, C, generator=g), torch.randn(B, Nk, C, generator=g)
+    nkp = (Nk + 7) // 8 * 8
+    vt = torch.zeros(B, C, nkp)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    o = ops.flash_attn(q.to(cuda), k.to(cuda), vt.to(cuda), H, D)
+    sp = lambda t: t.double().unflatten(2, (H, D)).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).flatten(2)
+    assert rel_l2(o, ref) < 2e-6
+
+
+def _pipeline_f32(cuda, unet_cfg, steps, cond=None):
+    from lbm_amd.models.embedders import ConditionerWrapper
+    from lbm_amd.models.lbm import LBMConfig, LBMModel
+    from lbm_amd.models.schedulers import FlowMatchEulerDiscreteScheduler
+    from lbm_amd.models.unets import DiffusersUNet2DCondWrapper
+    from lbm_amd.models.vae import AutoencoderKL, AutoencoderKLDiffusers, AutoencoderKLDiffusersConfig
+    from oracle import bridge_ref as br
+    from oracle import diffusers_ref as dr
+    torch.manual_seed(0)
+    unet = DiffusersUNet2DCondWrapper(**unet_cfg)
+    core = AutoencoderKL(scaling_factor=0.13025)
+    usd, vsd = f32_state(unet), f32_state(core)
+    vae = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version="unused", tiling_size=(128, 128)), vae_model=core)
+    model = LBMModel(LBMConfig(bridge_noise_sigma=0.005), denoiser=unet, vae=vae, conditioner=ConditionerWrapper([]),
+                     sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                     training_noise_scheduler=FlowMatchEulerDiscreteScheduler()).to(cuda).to(F32).eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    enc_eps = torch.randn(1, 4, 16, 16, generator=g)
+    eps_list = [torch.randn(1, 4, 16, 16, generator=g) for _ in range(steps - 1)]
+    with torch.no_grad():
+        z_ref = dr.posterior_sample(dr.vae_encode_moments(vsd, x), enc_eps) * 0.13025
+        lat_ref = br.sample(z_ref, lambda s, t: dr.unet_forward(usd, unet_cfg, s, t), steps, eps_list, 0.005)
+        img_ref = dr.vae_decode(vsd, lat_ref / 0.13025)
+        z = model.vae.encode(x.to(cuda), eps=enc_eps.to(cuda))
+        assert z.dtype == F32
+        old, model.vae = model.vae, None
+        lat = model.sample(z, num_steps=steps, eps_list=[e.to(cuda) for e in eps_list])
+        model.vae = old
+        img = model.sample(z, num_steps=steps, eps_list=[e.to(cuda) for e in eps_list])
+    return rel_l2(z, z_ref), rel_l2(lat, lat_ref), rel_l2(img, img_ref), psnr01(img, img_ref)
+
+
+@pytest.mark.parametrize("steps", [1, 4])
+def test_pipeline_fp32_mode(cuda, steps):
+    """encode -> n-step sample -> decode entirely in f32: latent relative L2 <= 1e-5 against the fp32 oracle"""
+    ez, el, ei, psnr = _pipeline_f32(cuda, SMALL_UNET, steps)
+    print(f"fp32 mode {steps}-step: encode {ez:.2e}, latent {el:.2e}, image {ei:.2e}, PSNR {psnr:.1f} dB")
+    assert ez < 1e-5 and el < 1e-5          # the stated fp32 bound is on the latent
+    # the decoded image has no fp32 rel-L2 bound of its own (PSNR >= 40 dB); both sides carry f32 rounding through the
+    # ~60 layers of the decoder, and the two differ by about the sum of the two
+    assert ei < 5e-5 and psnr > 100.0
+
+
+def test_unet_sd15_style_fp32_mode(cuda):
+    """SD1.5-style denoiser (1x1-conv projections, head dims 40 / 80, 5-token cross-attention) in f32"""
+    from lbm_amd.models.unets import DiffusersUNet2DCondWrapper
+    from oracle import diffusers_ref as dr
+    cfg = dict(SD15_STYLE, cross_attention_dim=768)
+    torch.manual_seed(4)
+    m = DiffusersUNet2DCondWrapper(**cfg)
+    sd = f32_state(m)
+    m = m.to(cuda).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, cfg["in_channels"], 16, 16, generator=g)
+    ctx = torch.randn(2, 5, 768, generator=g)
+    ts = torch.tensor([1000.0, 250.0])
+    ref = dr.unet_forward(sd, cfg, x, ts, encoder_hidden_states=ctx)
+    with torch.no_grad():
+        out = m(sample=x.to(cuda), timestep=ts.to(cuda), conditioning={"cond": {"crossattn": ctx.to(cuda)}})
+    assert out.dtype == F32 and rel_l2(out, ref) < 1e-5
