@@ -418,6 +418,21 @@ def test_get_model_evaluate_end_to_end(cuda, tmp_path):
     print(f"get_model/evaluate 1024x1024 (bucket of a 512x512 input): encode rel-L2 {zerr:.4f}, image PSNR {psnr:.1f} dB")
     assert zerr < 1e-2
     assert psnr >= 40.0
+    # the same checkpoint in fp32 mode (BASELINE config 1 is an fp32 configuration): get_model(torch_dtype=float32)
+    del model
+    torch.cuda.empty_cache()
+    model = get_model(str(ckpt), torch_dtype=torch.float32, device="cuda")
+    assert model.denoiser.conv_in.weight.dtype == torch.float32
+    vae_encode = model.vae.encode
+    model.vae.encode = encode_with_eps
+    out32 = evaluate(model, pil, num_sampling_steps=1)
+    got8 = np.asarray(out32)
+    mse = float(((got8.astype(np.float64) - ref8.astype(np.float64)) ** 2).mean()) / 255.0 ** 2
+    psnr32 = 10 * math.log10(1.0 / max(mse, 1e-12))
+    zerr32 = rel_l2(seen["z"], z_ref)
+    print(f"fp32 mode: encode rel-L2 {zerr32:.2e}, image PSNR {psnr32:.1f} dB (8-bit outputs)")
+    assert seen["z"].dtype == torch.float32 and zerr32 < 1e-5
+    assert psnr32 >= 70.0
 
 
 def test_full_size_pipeline_is_batch_consistent(cuda):
