@@ -60,7 +60,7 @@ class LinearFn(torch.autograd.Function):
             xc = x2.contiguous() if x2.stride(1) != 1 else x2
             sink = _grad_sink(ctx.mod.weight)
             if sink is not None and dy2.shape[1] == N and xc.shape[1] == K:
-                sink.write([ctx.mod.weight], lambda out: ops.gemm_tn(dy2, xc, out=out))
+                sink.write([ctx.mod.weight], lambda out: ops.gemm_tn(dy2, xc, out=out), reads=(dy2, xc))
             else:
                 dw = ops.gemm_tn(dy2, xc, out_dtype=weight.dtype)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -108,14 +108,15 @@ class Conv2dFn(torch.autograd.Function):
             if dx.shape[-1] != Cs:
                 dx = dx[..., :Cs].contiguous() if dx.shape[-1] > Cs else torch.nn.functional.pad(dx, (0, Cs - dx.shape[-1]))
         if ctx.needs_input_grad[1]:
-            col_t = ops.im2col_t(x, cin_p, KH, KW, stride, pad, up2, (OH, OW))     # [KH*KW*cin_p, M]
-            dwk = ops.gemm_tn_t(ops.transpose(dy2), col_t, out_dtype=torch.float32)   # [npad, KH*KW*cin_p]
-            dwv = dwk[:N].view(N, KH * KW, cin_p)[:, :, :Cin].permute(0, 2, 1)        # [N, Cin, KH*KW] strided view
+            def wgrad():
+                col_t = ops.im2col_t(x, cin_p, KH, KW, stride, pad, up2, (OH, OW))     # [KH*KW*cin_p, M]
+                dwk = ops.gemm_tn_t(ops.transpose(dy2), col_t, out_dtype=torch.float32)   # [npad, KH*KW*cin_p]
+                return dwk[:N].view(N, KH * KW, cin_p)[:, :, :Cin].permute(0, 2, 1)       # [N, Cin, KH*KW] strided view
             sink = _grad_sink(ctx.mod.weight)
             if sink is not None:
-                sink.write([ctx.mod.weight], lambda out: out.view(N, Cin, KH * KW).copy_(dwv))
+                sink.write([ctx.mod.weight], lambda out: out.view(N, Cin, KH * KW).copy_(wgrad()), reads=(x, dy2))
             else:
-                dw = dwv.reshape(N, Cin, KH, KW).to(weight.dtype)
+                dw = wgrad().reshape(N, Cin, KH, KW).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy2, out_dtype=weight.dtype)[0, :N]
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -305,7 +306,7 @@ class SelfAttnQKVFn(torch.autograd.Function):
         if all(ctx.needs_input_grad[1:4]) and sink is not None and sink.stacked(ws, mod._qkv_stack()[0]):
             # the three weights are one [3C, K] block of the flat buffer, and so are their gradient slots
             xc = x2.contiguous() if x2.stride(1) != 1 else x2
-            sink.write(ws, lambda out: ops.gemm_tn(d2, xc, out=out))
+            sink.write(ws, lambda out: ops.gemm_tn(d2, xc, out=out), reads=(d2, xc))
         elif any(ctx.needs_input_grad[1:4]):
             dw = ops.gemm_tn(d2, x2.contiguous() if x2.stride(1) != 1 else x2, out_dtype=ctx.wdt)   # [3C, K]
             dws = [dw[cols[r]:cols[r] + C, :x.shape[-1]] if ctx.needs_input_grad[1 + i] else None

@@ -131,23 +131,31 @@ class GradSink:
                 and stack.untyped_storage().data_ptr() == self.group.flat.untyped_storage().data_ptr()
                 and stack.numel() == sum(p.numel() for p in params))
 
-    def write(self, params, compute):
+    def write(self, params, compute, reads=()):
         """compute(out) fills ``out``: the gradient slot of ``params`` (several = one contiguous block, lowest
-        address first)."""
+        address first).  ``reads``: the tensors ``compute`` consumes (kept alive for the side stream when the
+        reducer runs weight gradients on one, see GradReducer.use_side_stream)."""
         first = min(params, key=lambda p: self.slot[id(p)][0])
         o = self.slot[id(first)][0]
         n = sum(p.numel() for p in params)
         rows = sum(p.shape[0] for p in params)
         out = self.group.grad[o:o + n].view(rows, *first.shape[1:])
         fresh = [id(p) not in self.reducer.written for p in params]
-        if all(fresh):
-            compute(out)
-        elif not any(fresh):
-            tmp = torch.empty_like(out)
-            compute(tmp)
-            out.add_(tmp)
-        else:
-            raise RuntimeError("stacked parameters must be written together")
+
+        def run():
+            if all(fresh):
+                compute(out)
+            elif not any(fresh):
+                tmp = torch.empty_like(out)
+                compute(tmp)
+                out.add_(tmp)
+            else:
+                raise RuntimeError("stacked parameters must be written together")
+            self._mark(params, fresh)
+
+        self.reducer.on_side_stream(run, reads)
+
+    def _mark(self, params, fresh):
         for p, f in zip(params, fresh):
             if f:
                 self.reducer.written.add(id(p))
@@ -181,6 +189,12 @@ class GradReducer:
         self.active = False
         self.written = set()
         self.touched = [set() for _ in groups]
+        # optional weight-gradient side stream (LBM_WGRAD_STREAM=1).  Off by default: measured on the 512x512 batch-8
+        # step it is 4-5 % SLOWER (172 vs 164 ms) -- nearly every kernel of the step already fills the chip, so two
+        # streams have little to overlap and the per-gradient event traffic costs more than the tails it hides
+        self._side = None
+        self._main = None
+        self.use_side_stream = groups[0].flat.is_cuda and os.environ.get("LBM_WGRAD_STREAM", "0") == "1"
         for gi, g in enumerate(groups):
             sink = GradSink(self, g) if direct_grads else None
             for pi, p in enumerate(g.params):
@@ -189,7 +203,33 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(self._make_hook(g, pi))
         self._gindex = {id(g): gi for gi, g in enumerate(groups)}
 
+    def on_side_stream(self, fn, reads=()):
+        """Runs ``fn`` (kernel launches) on the side stream, ordered after everything enqueued so far on the current
+        stream; ``reads``: tensors ``fn`` consumes, kept from being recycled until the side stream is done with them."""
+        if not self.use_side_stream:
+            return fn()
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=main.device)
+        self._main = main
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fn()
+        for t in reads:
+            if t is not None and t.is_cuda:
+                t.record_stream(self._side)
+
+    def _join_streams(self):
+        """the current stream waits for the backward pass's main and side streams (gradients are written on both)"""
+        if self._side is None:
+            return
+        cur = torch.cuda.current_stream()
+        for st in (self._side, self._main):
+            if st is not None and st != cur:
+                cur.wait_stream(st)
+
     def _send(self, group, bucket):
+        self._join_streams()
         s, e, _ = group.buckets[bucket]
         if self.mode == "reduce_scatter":
             a, b = group.shard_of(bucket, self.rank)
@@ -231,6 +271,7 @@ class GradReducer:
         Returns (factor that turns the summed gradient into the mean, per-group update ranges in flat coordinates
         restricted to this rank's slices, loss averaged over the ranks or None)."""
         self.active = False
+        self._join_streams()
         mean_loss = None if loss is None else loss.detach().float()
         if self.dist is not None:
             # parameters that received no gradient this step never fired their hook: exchange what is left
