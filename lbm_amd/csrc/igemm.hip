@@ -615,8 +615,7 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {64, 64},      // 13: tile 3 double-buffered
                           {128, 128},    // 14: tile 0 double-buffered
                           {384, 128},    // 15: 12 waves (64x64 per wave), shared activation rows (ROWA): 3x3 stride-1 convolutions
-                          {192, 128},    // 16: 8 waves (48x64 per wave), double-buffered, two workgroups per CU (2 x 80 KB of LDS)
-                          {256, 256}};   // 17: 4 waves (128x128 per wave, accumulators in AGPRs): half the LDS reads per MFMA of 64x64 wave tiles
+                          {192, 128}};   // 16: 8 waves (48x64 per wave), double-buffered, two workgroups per CU (2 x 80 KB of LDS)
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
@@ -783,7 +782,6 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 14: launch<128, 128, 2, 2, true, false, 2>(d, s); break;
     case 15: launch<384, 128, 6, 2, true, false, 1, true>(d, s); break;
     case 16: launch<192, 128, 4, 2, true, false, 2>(d, s); break;
-    case 17: launch<256, 256, 2, 2, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }

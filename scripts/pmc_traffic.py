@@ -1,7 +1,7 @@
 """HBM traffic of the implicit-GEMM launches of the headline bench step from two rocprofv3 --pmc passes.
 
-  cd /tmp && rocprofv3 --pmc FETCH_SIZE -d <dir>/fetch -o out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
-  cd /tmp && rocprofv3 --pmc WRITE_SIZE -d <dir>/write -o out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+  cd /tmp && rocprofv3 --pmc FETCH_SIZE -d <dir>/fetch -o out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
+  cd /tmp && rocprofv3 --pmc WRITE_SIZE -d <dir>/write -o out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras
   python scripts/pmc_traffic.py <dir>/fetch/out_counter_collection.csv <dir>/write/out_counter_collection.csv > profiles/<name>.json
 
 The bench runs one set-up pass, one warm-up step and one timed step: the set-up pass launches the same kernels,
@@ -26,7 +26,7 @@ write_b = write_kb * 1024 / nw
 launches_per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 772
 print(json.dumps({
     "what": "HBM traffic of the igemm_kernel launches of one headline bench step (1024^2, batch 16, 1 NFE), rocprofv3 --pmc, separate passes",
-    "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline   (second pass: --pmc WRITE_SIZE)",
+    "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-extras   (second pass: --pmc WRITE_SIZE)",
     "workload": {"res": 1024, "batch": 16, "nfe": 1},
     "igemm_launches": nf, "FETCH_SIZE_KB_sum": fetch_kb, "WRITE_SIZE_KB_sum": write_kb,
     "correction": "gfx950: FETCH_SIZE tallies the 16-byte-per-lane buffer_load...lds reads at half their size -> x2; WRITE_SIZE exact",
