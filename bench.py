@@ -139,6 +139,25 @@ def extra_inference(model, device, rank, world, dist, res, batch, nfe, steps):
             "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / world / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
 
 
+def extra_fp32(device, rank, world, dist, res, batch, steps):
+    """BASELINE config 1's dtype: the same model held in f32 (fp32 mode, exact-f32 MFMA), 1 NFE, batch 1 per GPU"""
+    from lbm_amd import ops
+    model = build_model(device, res).to(torch.float32)
+    g = torch.Generator().manual_seed(7 + rank)
+    images = (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(device)
+    eps = torch.randn(batch, 4, res // 8, res // 8, generator=g).to(device)
+    out = one_step(model, images, eps, 1)
+    el = _timed_steps(lambda: one_step(model, images, eps, 1), steps, dist, device)
+    assert out.dtype == torch.float32 and bool(torch.isfinite(out).all())
+    ips = batch * world * steps / el
+    tf = ips * sum(FLOPS_T[res])
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": f"{res}x{res}, 1-NFE, batch {batch}/GPU x{world}, fp32 mode (f32 activations, v_mfma_f32_32x32x2_f32)",
+            "value": round(ips, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 1), "steps": steps,
+            "tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / world / 157.3, 4)}
+
+
 def extra_training(model, device, rank, world, dist, res, batch, steps):
     """bridge-matching training step: two frozen VAE encodes, interpolant, UNet forward + backward, latent loss,
     gradient exchange over RCCL when world > 1, fused AdamW.  7.31 TFLOP per 512x512 sample (2 * 1.117 + 3 * 1.693)."""
@@ -279,8 +298,10 @@ def main():
     state["roofline"], state["secondary"] = roofline, secondary
     if not args.no_extras and (args.res, args.nfe) == (1024, 1):
         # per-GPU shares of the other BASELINE configurations, every rank taking part (same barrier / max-over-ranks
-        # timing as the headline): C3 = 4-step sampling at 1024^2, C5 = 2048^2, C4 = the training step
-        for name, fn in (("nfe4_1024_b8", lambda: extra_inference(model, device, rank, world, dist, 1024, 8, 4, 2)),
+        # timing as the headline): C1 = 512^2 batch 1 in fp32, C3 = 4-step sampling at 1024^2, C5 = 2048^2, C4 = the
+        # training step
+        for name, fn in (("c1_512_b1_fp32", lambda: extra_fp32(device, rank, world, dist, 512, 1, 2)),
+                         ("nfe4_1024_b8", lambda: extra_inference(model, device, rank, world, dist, 1024, 8, 4, 2)),
                          ("res2048_b8", lambda: extra_inference(model, device, rank, world, dist, 2048, 8, 1, 1)),
                          ("train_512_b8", lambda: extra_training(model, device, rank, world, dist, 512, 8, 3))):
             try:

@@ -81,7 +81,8 @@ class UNet2DModel(nn.Module, _Cached):
         if t.numel() == 1:
             t = t.expand(B)
         t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in, dtype=self.conv_in.weight.dtype if self.conv_in.weight.dtype == torch.float32 else torch.bfloat16)
-        if training(self.time_embedding.linear_1.weight):
+        time_params = list(self.time_embedding.parameters()) + [p for r in self._resnets() for p in r.time_emb_proj.parameters()]
+        if training(*time_params):      # any trainable parameter on the time path
             from ...autograd import SiluFn
             e = SiluFn.apply(self.time_embedding.linear_2(SiluFn.apply(self.time_embedding.linear_1(t_emb))))
             return {id(r): r.time_emb_proj(e) for r in self._resnets()}
@@ -100,7 +101,7 @@ class UNet2DModel(nn.Module, _Cached):
         if class_labels is not None:
             raise NotImplementedError("class conditioning is not used by the reference's builders")
         B = sample.shape[0]
-        train = training(sample, self.conv_in.weight)
+        train = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters()))
         tv = self._time_vectors(timestep, B, sample.device)
         if train and sample.requires_grad:
             from ...autograd import NchwToNhwcFn

@@ -352,7 +352,10 @@ class UNet2DConditionModel(nn.Module, _Cached):
         if t.numel() == 1:
             t = t.expand(B)
         t_emb = ops.timestep_embedding(t.contiguous(), self.temb_in, dtype=self.compute_dtype)
-        if training(self.time_embedding.linear_1.weight):
+        # differentiable route when ANY parameter on the time path trains (the embedding MLP or a resnet's projection):
+        # a single sentinel would silently starve the others of their gradient
+        time_params = list(self.time_embedding.parameters()) + [p for r in self._resnets() for p in r.time_emb_proj.parameters()]
+        if training(*time_params):
             from ...autograd import SiluFn
             e = SiluFn.apply(self.time_embedding.linear_2(SiluFn.apply(self.time_embedding.linear_1(t_emb))))
             return {id(r): r.time_emb_proj(e) for r in self._resnets()}
@@ -375,7 +378,9 @@ class UNet2DConditionModel(nn.Module, _Cached):
                 or mid_block_additional_residual is not None or down_intrablock_additional_residuals is not None:
             raise NotImplementedError("class labels / added conditions / ControlNet residuals are not used by the reference's builders")
         B = sample.shape[0]
-        train = training(sample, self.conv_in.weight)
+        # differentiable route when the input or ANY parameter of the model wants a gradient (a trainable_params
+        # pattern may freeze conv_in while the blocks train)
+        train = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters()))
         tv = self._time_vectors(timestep, B, sample.device)
         if train and sample.requires_grad:
             from ...autograd import NchwToNhwcFn

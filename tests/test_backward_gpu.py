@@ -524,6 +524,22 @@ def test_training_checkpoint_resume(cuda, tmp_path):
     assert all(k.startswith("model.") for k in sd) and "model.denoiser.conv_in.weight" in sd
 
 
+def test_frozen_input_layers_do_not_starve_the_rest(cuda):
+    """a trainable_params pattern that freezes conv_in and the time-embedding MLP: the forward still takes the
+    differentiable route, the remaining parameters (resnet time projections included) receive gradients"""
+    model = _toy_lbm(cuda)
+    den = model.denoiser
+    for p in list(den.conv_in.parameters()) + list(den.time_embedding.parameters()):
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(2)
+    z, zs, eps = (torch.randn(2, 4, 32, 32, generator=g).to(BF).to(cuda) for _ in range(3))
+    out = model({"target": z, "source": zs}, bridge_eps=eps, timesteps=torch.tensor([500, 750], device=cuda))
+    out["loss"].backward()
+    proj = den.down_blocks[0].resnets[0].time_emb_proj.weight
+    assert proj.grad is not None and float(proj.grad.float().abs().sum()) > 0
+    assert den.conv_out.weight.grad is not None and den.conv_in.weight.grad is None
+
+
 def test_fit_loop_resume_and_rccl_exchange(cuda, tmp_path):
     """lbm_amd.trainer.fit: 4 steps straight through == 2 steps, stop, resume from the checkpoint the resolver picks,
     2 more steps (bit-identical parameters); then the same 4 steps through a one-rank RCCL process group with the
