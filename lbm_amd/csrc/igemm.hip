@@ -33,6 +33,8 @@ __device__ unsigned long long igemm_dbg[65536 * 8];
 #endif
 
 
+__device__ __forceinline__ bool lbmk_aligned_dev(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
+
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
 // output row / packed column are mbase / nbase.
 // Loads are batched ahead of the stores on purpose: `out` may alias anything as far as the compiler
@@ -80,6 +82,83 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     // GroupNorm partial sums of this wave's 64-row strip (bf16-rounded values, as a separate
     // statistics pass over the stored tensor would read them)
     constexpr bool gn = GNS && MI == 4;   // separate instantiation: the 8 extra accumulators do not fit the plain kernels' budget
+    // Wide form (bf16 output, 16-byte aligned rows, an even number of column groups): lanes l and l ^ 16 hold
+    // channels 4 lq ... + 3 of the same pixel for every column group.  v_permlane16_swap between the packed values of
+    // groups j and j + 1 leaves the even-lq lane with 8 consecutive channels of group j and the odd-lq lane with 8 of
+    // group j + 1, so a store is 16 bytes per lane and 64 contiguous bytes per pixel: half the store instructions.
+    // The residual is read the same way and swapped back into the accumulator layout.
+    // (instantiations that reduce GroupNorm statistics take the wide form only: the host checks its conditions)
+    const bool wide = (GNS && NI % 2 == 0) ||
+                      ((NI % 2 == 0) && !geglu && !p.out_f32 && (n_out & 7) == 0 && (p.ldo & 7) == 0 && (zo & 7) == 0 &&
+                       lbmk_aligned_dev(p.out, 16) && (!res || ((p.ldr & 7) == 0 && (zr & 7) == 0 && lbmk_aligned_dev(p.residual, 16))));
+    if (wide) {
+      constexpr int NP2 = NI / 2 > 0 ? NI / 2 : 1;
+      u32x4 rw[NP2];
+      u16x4 rv[NI];
+      // first channel of this lane's 16-byte segment of column-group pair jp
+      auto wcol = [&](int jp) { return nbase + (2 * jp + (lq & 1)) * 16 + (lq & 2) * 4; };
+      auto fetchw = [&](int i) {
+        const int m = mbase + i * 16 + lr;
+        const bool row_ok = m < p.M;
+        const int bimg = (rowvec && row_ok) ? m / ohw : 0;
+#pragma unroll
+        for (int jp = 0; jp < NI / 2; ++jp) {
+          const int c = wcol(jp);
+          rw[jp] = (res && row_ok && c < n_out) ? *(const u32x4*)(res + (int64_t)m * p.ldr + c) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int no = out_col(j);
+          rv[j] = (rowvec && row_ok && no < n_out) ? *(const u16x4*)(rowvec + (int64_t)bimg * p.rowvec_ld + no) : u16x4{{0, 0, 0, 0}};
+        }
+      };
+      if (has_add) fetchw(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (has_add) {
+#pragma unroll
+          for (int jp = 0; jp < NI / 2; ++jp) {
+            const auto t0 = __builtin_amdgcn_permlane16_swap(rw[jp][0], rw[jp][2], false, false);
+            const auto t1 = __builtin_amdgcn_permlane16_swap(rw[jp][1], rw[jp][3], false, false);
+            const unsigned ra[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};   // [group j / j + 1][channel pair]
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned w = ra[jj][e >> 1];
+                acc[i][2 * jp + jj][e] += __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16)) + bf2f(rv[2 * jp + jj].v[e]);
+              }
+          }
+          if (i + 1 < MI) fetchw(i + 1);
+        }
+        const int m = mbase + i * 16 + lr;
+        const bool row_ok = m < p.M;
+#pragma unroll
+        for (int jp = 0; jp < NI / 2; ++jp) {
+          unsigned pk[2][2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * jp + jj;
+            bf16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[i][j][e];
+              if (p.act == LBMK_ACT_SILU) v = silu_f(v);
+              else if (p.act == LBMK_ACT_RELU) v = fmaxf(v, 0.f);
+              o[e] = f2bf(v);
+              if (gn) acc[i][j][e] = bf2f(o[e]);   // keep the stored (rounded) value for the statistics pass below
+            }
+            pk[jj][0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
+            pk[jj][1] = (unsigned)o[2] | ((unsigned)o[3] << 16);
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          const int c = wcol(jp);
+          if (row_ok && c < n_out)
+            *(u32x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+    } else {
     u16x4 rr[NI], rv[NI];
     auto fetch = [&](int i) {
       const int m = mbase + i * 16 + lr;
@@ -134,6 +213,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           }
         }
       }
+    }
     }
     if (gn && mbase < p.M) {
       const int cpg = p.N / p.gn_groups;        // 4, 8 or 16 channels: whole groups inside a 16-column tile
@@ -202,20 +282,27 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // (filter row, 64-channel chunk) pair is staged once as BM + 8 consecutive pixels of the flattened NHWC input and
 // the taps kw = 0, 1, 2 read it at row offsets 0, 1, 2: a third of the activation traffic.  Taps that fall outside
 // the image are zeroed on the fragment after the LDS read (per-lane 9-bit masks; waves without such pixels skip it).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false, bool ROWA = false>
+// PP (8 waves, Cin % 64 == 0, 1x1 or 3x3 / stride 1 / 'same' padding): ping-pong schedule.  Waves 0-3 and 4-7 (one of
+// each group per SIMD) run half a K-tile apart: while one group reads its fragments of a K-tile from LDS into registers,
+// the other issues the MFMAs of the tile it read in the previous phase, so the matrix pipe of every SIMD always has one
+// wave feeding it and no wave's LDS latency is exposed.  An LDS-DMA instruction blocks its wave for on the order of a
+// hundred cycles, so every wave issues its loads in its READ phase only, behind its fragment reads.  For that to meet the
+// landing deadlines the activation tile has two stage buffers whose halves are staged by the group that does not read
+// them, and the weight tile (read by both groups) has three.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false, bool ROWA = false, bool PP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 3) / 4) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
-  constexpr int RPP = NT / 8;                   // tile rows staged by one LDS-DMA instruction of the block
+  constexpr int RPP = PP ? 32 : NT / 8;         // tile rows staged by one LDS-DMA instruction of the block (PP: of waves 0-3)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int AI = BM / RPP;                  // LDS-DMA loads per thread for the A tile
-  constexpr int BI = (BN + RPP - 1) / RPP;      // LDS-DMA loads per thread for the B tile (last one partial when BN % RPP != 0)
+  constexpr int AI = PP ? BM / 64 : BM / RPP;   // LDS-DMA loads per thread for the A tile (PP: for the other group's half)
+  constexpr int BI = (BN + RPP - 1) / RPP;      // LDS-DMA loads per thread for the B tile (last one partial when BN % RPP != 0; PP: shared by the groups)
   constexpr int STAGE = (BM + BN) * 128;        // bytes of one K-tile (64 deep) of both operands
   static_assert(WM % 16 == 0 && WN % 16 == 0 && BM % RPP == 0, "tile shape");
   // all LDS in ONE array: a second __shared__ object makes hipcc drain vmcnt before every ds_read
   constexpr int ABYTES = (BM + 8) * 128;        // ROWA: one activation ring slot (BM + 8 pixels x 64 channels)
-  __shared__ __attribute__((aligned(16))) char smem[ROWA ? 2 * ABYTES + 2 * BN * 128 : (DBUF ? 2 : 1) * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[ROWA ? 2 * ABYTES + 2 * BN * 128 : PP ? 2 * BM * 128 + 3 * BN * 128 : (DBUF ? 2 : 1) * STAGE];
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -253,7 +340,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   // reads zeros, which is how padding taps, rows past M / N and the K tail are produced (no
   // branches, no 64-bit address arithmetic in the K loop).
   const int slot = t & 7;          // 16-byte slot inside a 128-byte LDS row
-  const int rsub = t >> 3;         // row inside an RPP-row group
+  const int rsub = (PP ? (t & 255) : t) >> 3;   // row inside an RPP-row group
+  const int swave = PP ? (wave & 3) : wave;     // staging wave: rows swave * 8 ... + 7 of every RPP-row group
+  const int sgrp = PP ? (wave >> 2) : 0;        // PP: waves 0-3 stage activation rows BM / 2 ..., waves 4-7 rows 0 ...
   const int kk = (slot ^ ((rsub >> 1) & 7)) * 8;   // swizzled k offset inside the 64-wide tile
   const int ohw = p.OH * p.OW;
   const int IHe = p.up2 ? 2 * p.IH : p.IH;
@@ -288,7 +377,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     a_bytes = (int)rem;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int m = m0 + rs + RPP * i;
+      const int m = m0 + rs + RPP * i + (PP ? (1 - sgrp) * (BM / 2) : 0);
       unsigned mask = 0, vo = 0;
       if (m < p.M) {
         const int b = m / ohw, r2 = m - b * ohw;
@@ -309,7 +398,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
         }
         const int pix = (b - b0) * p.IH * p.IW + (ry - by0) * p.IW + rx;
         vo = (unsigned)(pix * p.a_cs + p.a_coff + (uni ? kk_ : 0)) * 2u;
-      }
+        if constexpr (PP) {   // no mask register: 4 edge bits ride in the (zero) low bits of the 16-byte aligned offset
+          if (p.KW == 3) vo |= (oy == 0 ? 1u : 0u) | (oy + 1 == p.OH ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox + 1 == p.OW ? 8u : 0u);
+        }
+      } else if constexpr (PP) vo = OOB;
       a_vo[i] = vo;
       a_mask[i] = mask;
     }
@@ -443,6 +535,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     }
   };
 
+  // PP: group g (0: waves 0-3, 1: waves 4-7) stages the activation rows of the OTHER group and every second 32-row
+  // piece of the weight tile.  Tap (kh, kw) of a pixel is outside the image iff the pixel has one of the edge bits
+  // sel(kh, kw); the weight rows are an arithmetic progression, so one offset register serves all of them.
+  auto stage_pp = [&](const int g, int kt, char* abuf, char* wbuf) __attribute__((always_inline)) {
+    int kh = 0, kw = 0;
+    unsigned sel = 0;
+    if (p.KW == 3) {
+      kh = (tap_s * 11) >> 5;
+      kw = tap_s - kh * 3;
+      sel = (kh == 0 ? 1u : kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : kw == 2 ? 8u : 0u);
+    }
+    const unsigned soff = (unsigned)((kh * p.IW + kw) * p.a_cs + chb_s) * 2u;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const unsigned vo = (a_vo[i] & sel) ? OOB : (a_vo[i] & ~15u) + soff;
+      buffer_lds16(a_base, a_bytes, vo, 0, abuf + ((1 - g) * (BM / 2) + swave * 8 + RPP * i) * 128);
+    }
+    const bool tap_major = p.k_order != 0;
+    const int t1 = tap_s + 1, c1 = chb_s + 64;
+    const bool wrap = tap_major ? (t1 == ntaps) : (c1 >= p.Cin);
+    const int nt = tap_major ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
+    const int nc = tap_major ? (wrap ? c1 : chb_s) : (wrap ? 0 : c1);
+    tap_s = nt;
+    chb_s = nc;
+    const unsigned wstep = (unsigned)(RPP * p.Kp) * 2u;
+#pragma unroll
+    for (int i = g; i < BI; i += 2)
+      buffer_lds16(W, w_bytes, w_vo[0] + wstep * (unsigned)i, kt << 7, wbuf + (swave * 8 + RPP * i) * 128);
+  };
+
   // MFMA over one staged 64-deep tile, software-pipelined inside the wave: a tile is 2*NI steps of
   // MI MFMAs (one B fragment against all A fragments of a 32-deep k-step).  Each step first issues
   // the ds_read of the NEXT step's B fragment and, during the first k-step, one share of the second
@@ -490,7 +612,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
 
   const int nkt = (p.K + 63) >> 6;
   if constexpr (ROWA) {
-    // Macro-step g = (filter row kh, channel chunk): its activation slot serves the three K-steps kw = 0, 1, 2.
+    // Macro-step g = (channel chunk, filter row kh): its activation slot serves the three K-steps kw = 0, 1, 2.
     // Weights: two stage buffers, tile of step s + 1 loaded under the MFMAs of step s.  Activations: two slots, the
     // pieces of macro-step g + 1 spread over the three steps of macro-step g (its slot was last read in macro-step
     // g - 1).  One barrier per K-step, as in the double-buffered loop.
@@ -524,8 +646,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int g = 0; g < ng; ++g) {
-      int nkh = kh, nchb = chb + 64;
-      if (nchb >= p.Cin) { nchb = 0; ++nkh; }
+      // chunk-major walk (all three filter rows of a channel chunk, then the next chunk): with chunk-major packed
+      // weights the products are summed in the same order as in the per-tap kernels, so every tile shape returns
+      // the same bits for a layer and the automatic tile choice cannot make a result depend on the batch size
+      int nkh = kh + 1, nchb = chb;
+      if (nkh == 3) { nkh = 0; nchb += 64; }
       const bool has_next = g + 1 < ng;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
@@ -570,6 +695,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     return;
+  } else if constexpr (PP) {
+    static_assert(NW == 8 && FAST && DBUF, "ping-pong schedule: 8 waves, uniform taps, two stage buffers");
+    // Phase p ends with a barrier.  Group 0 reads K-tile k in phase 2k and multiplies it in phase 2k + 1; group 1 reads
+    // it in phase 2k + 1 and multiplies in phase 2k + 2.  In its read phase of tile k, group 0 issues its share of tile
+    // k + 1 and group 1 its share of tile k + 2; each waits for its loads at the end of its next multiply phase, which
+    // is at least one full phase before anyone reads them.  Both groups pass the same number (2 nkt) of barriers.
+    // Barriers inside the loop are bare s_barrier instructions: __syncthreads() carries a fence that drains the
+    // vector-memory counter, which would make the staging waves wait for their LDS-DMA loads in the phase that issues
+    // them.  The explicit counter waits before each barrier order exactly what the next phase depends on.
+    const int grp = wave >> 2;
+    bf16x8 fa[2][MI], fb[2][NI];
+    char* const wbase = smem + 2 * BM * 128;
+    auto abuf = [&](int k) __attribute__((always_inline)) { return smem + (k & 1) * (BM * 128); };
+    auto read_tile = [&](const char* ab, const char* wb) __attribute__((always_inline)) {
+      const char* pa = ab + rdA;
+      const char* pb = wb + (wn * WN + lr) * 128;
+      const int off0 = (lq ^ rd_swz) << 4, off1 = ((4 + lq) ^ rd_swz) << 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        fa[0][i] = *(const bf16x8*)(pa + i * 16 * 128 + off0);
+        fa[1][i] = *(const bf16x8*)(pa + i * 16 * 128 + off1);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        fb[0][j] = *(const bf16x8*)(pb + j * 16 * 128 + off0);
+        fb[1][j] = *(const bf16x8*)(pb + j * 16 * 128 + off1);
+      }
+    };
+    auto mfma_tile = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // w0 / w1 / w2: weight buffers of K-tiles kt, kt + 1, kt + 2 (kt mod 3 rotation)
+    char* w0 = wbase;
+    char* w1 = wbase + BN * 128;
+    char* w2 = wbase + 2 * BN * 128;
+    if (grp == 0) {
+      stage_pp(0, 0, abuf(0), w0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      DBG_T(2);
+      DBG_C(6);
+      for (int kt = 0; kt < nkt; ++kt) {
+        read_tile(abuf(kt), w0);
+        if (kt + 1 < nkt) stage_pp(0, kt + 1, abuf(kt + 1), w1);   // rows of group 1 last read in phase 2 kt - 1, weight buffer in 2 kt - 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* tw = w0; w0 = w1; w1 = w2; w2 = tw;
+      }
+    } else {
+      stage_pp(1, 0, abuf(0), w0);
+      if (nkt > 1) stage_pp(1, 1, abuf(1), w1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      __builtin_amdgcn_s_barrier();
+      for (int kt = 0; kt < nkt; ++kt) {
+        read_tile(abuf(kt), w0);
+        if (kt + 2 < nkt) stage_pp(1, kt + 2, abuf(kt), w2);        // rows of group 0 last read in phase 2 kt, weight buffer in 2 kt - 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < nkt) __builtin_amdgcn_s_barrier();
+        char* tw = w0; w0 = w1; w1 = w2; w2 = tw;
+      }
+    }
   } else if constexpr (DBUF) {
     // two stage buffers, ONE barrier per K-tile: the loads of tile kt+1 are issued before the MFMAs
     // of tile kt and land underneath them.  Buffer (kt+1)&1 was last read by tile kt-1, which every
@@ -615,7 +820,10 @@ const TileCfg kTiles[] = {{128, 128}, {128, 64}, {256, 16}, {64, 64}, {256, 64},
                           {64, 64},      // 13: tile 3 double-buffered
                           {128, 128},    // 14: tile 0 double-buffered
                           {384, 128},    // 15: 12 waves (64x64 per wave), shared activation rows (ROWA): 3x3 stride-1 convolutions
-                          {192, 128}};   // 16: 8 waves (48x64 per wave), double-buffered, two workgroups per CU (2 x 80 KB of LDS)
+                          {192, 128},    // 16: 8 waves (48x64 per wave), double-buffered, two workgroups per CU (2 x 80 KB of LDS)
+                          {256, 256},    // 17: 8 waves (64x128 per wave), ping-pong schedule
+                          {256, 160},    // 18: 8 waves (64x80 per wave), ping-pong schedule
+                          {256, 128}};   // 19: 8 waves (64x64 per wave), ping-pong schedule
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 inline bool fast_path(const lbmk_igemm_desc& d) { return d.Cin % 64 == 0; }
@@ -635,18 +843,30 @@ inline bool rowa_ok(const lbmk_igemm_desc& d) {
          d.Cin % 64 == 0 && d.batch == 1;
 }
 
-template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1, bool ROWA = false>
+// LBMK_NO_PP=1 keeps the automatic choice off the ping-pong tiles (same-box A/B runs)
+inline bool pp_enabled() {
+  static const bool on = getenv("LBMK_NO_PP") == nullptr;
+  return on;
+}
+// shapes the ping-pong kernels take: their staging keeps 4 edge bits per pixel instead of a 9-tap mask
+inline bool pp_ok(const lbmk_igemm_desc& d) {
+  if (d.Cin % 64) return false;
+  if (d.KH == 1) return d.pad_t == 0 && d.pad_l == 0;
+  return d.stride == 1 && !d.up2 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.IH && d.OW == d.IW;
+}
+
+template <int BM, int BN, int WMs, int WNs, bool DBUF, bool STAMP = false, int OCC = 1, bool ROWA = false, bool PP = false>
 void launch(const lbmk_igemm_desc& d, hipStream_t s) {
   const int tm = (d.M + BM - 1) / BM, tn = (d.N + BN - 1) / BN;
   int nblocks = tm * tn;
   if (ROWA && persist_enabled() && nblocks > lbmk_num_cus()) nblocks = lbmk_num_cus();   // one persistent workgroup per CU
   dim3 grid((unsigned)nblocks, 1, (unsigned)d.batch);
   if (d.gn_partial) {   // fused GroupNorm statistics: fast path only (checked by the caller)
-    if constexpr (BM / WMs == 64 && BN / WNs == 64 && !STAMP)
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true, ROWA>), grid, dim3(64 * WMs * WNs), 0, s, d);
+    if constexpr (BM / WMs == 64 && (BN / WNs == 64 || PP) && !STAMP)
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, false, OCC, true, ROWA, PP>), grid, dim3(64 * WMs * WNs), 0, s, d);
   } else if (fast_path(d))
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC, false, ROWA>), grid, dim3(64 * WMs * WNs), 0, s, d);
-  else if constexpr (!ROWA)
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, true, STAMP, OCC, false, ROWA, PP>), grid, dim3(64 * WMs * WNs), 0, s, d);
+  else if constexpr (!ROWA && !PP)
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WMs, WNs, DBUF, false, STAMP, OCC>), grid, dim3(64 * WMs * WNs), 0, s, d);
 }
 }  // namespace
@@ -715,7 +935,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
                  "igemm: shape M=%d N=%d Cin=%d %dx%d G=%d cannot carry fused GroupNorm statistics", d.M, d.N, d.Cin, d.OH, d.OW, d.gn_groups);
     LBMK_REQUIRE(!d.out_f32 && d.act != LBMK_ACT_GEGLU && d.batch == 1 && d.ldo % 4 == 0 && lbmk_aligned(d.gn_partial, 8),
                  "igemm: fused GroupNorm statistics need a bf16, non-GEGLU, unbatched output");
-    LBMK_REQUIRE((!d.residual || d.ldr % 4 == 0) && (!d.rowvec || d.rowvec_ld % 4 == 0), "igemm: gn statistics need 8-byte aligned rows");
+    LBMK_REQUIRE((!d.residual || (d.ldr % 8 == 0 && lbmk_aligned(d.residual, 16))) && (!d.rowvec || d.rowvec_ld % 4 == 0) &&
+                 d.ldo % 8 == 0 && d.N % 8 == 0 && lbmk_aligned(d.out, 16),
+                 "igemm: gn statistics need 16-byte aligned output / residual rows");
   }
 
   int tile = d.tile;
@@ -736,14 +958,22 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
                                    {0, 128, 128, 4, false, 2.8f, 4.8f, 0.55f, 0.34f}, {1, 128, 64, 4, false, 5.0f, 1.9f, 0.34f, 0.23f},
                                    {3, 64, 64, 8, false, 2.5f, 2.2f, 0.25f, 0.30f},   {12, 128, 64, 3, true, 1.9f, 4.5f, 0.34f, 0.55f},
                                    {13, 64, 64, 4, true, 3.3f, 2.0f, 0.24f, 0.42f},   {14, 128, 128, 2, true, 0.f, 7.9f, 0.20f, 0.84f},
-                                   {16, 192, 128, 2, true, 0.f, 12.0f, 0.58f, 0.90f}};   // offered to batched launches only (below)
+                                   {16, 192, 128, 2, true, 0.f, 12.0f, 0.58f, 0.90f},    // offered to batched launches only (below)
+                                   // ping-pong tiles: about 8 % less time per K step than their 16-wave counterparts (in-kernel
+                                   // stamps: 1.29 vs 1.41 us at 256x256), a longer epilogue (8 waves store the tile)
+                                   {17, 256, 256, 1, true, 0.f, 16.7f, 1.01f, 1.10f},  {18, 256, 160, 1, true, 0.f, 12.0f, 1.02f, 0.99f},
+                                   // shared activation rows, one persistent workgroup per CU (3x3 stride-1 convolutions)
+                                   {15, 384, 128, 1, true, 0.f, 7.9f, 1.0f, 1.0f}};
       const int cus = lbmk_num_cus();
       const int nkt = (d.K + 63) / 64;
       double best = 1e300;
       tile = 0;
       for (const Cand& c : cands) {
-        if (gn && !(c.tile == 0 || c.tile == 7 || c.tile == 8 || c.tile == 10 || c.tile == 14)) continue;   // statistics strips are 64 rows x 64 columns per wave
-        if (d.act == LBMK_ACT_GEGLU && c.tile == 11) continue;              // odd number of column groups per wave
+        if (gn && !(c.tile == 0 || c.tile == 7 || c.tile == 8 || c.tile == 10 || c.tile == 14 || c.tile == 15 || c.tile == 17)) continue;   // statistics strips are 64 rows per wave, column groups in pairs
+        if (d.act == LBMK_ACT_GEGLU && (c.tile == 11 || c.tile == 18)) continue;   // odd number of column groups per wave
+        if (d.act == LBMK_ACT_GEGLU && c.tile == 17) continue;              // measured behind tile 7: 8 waves run the GELU epilogue of 16
+        if ((c.tile == 17 || c.tile == 18) && !(pp_enabled() && pp_ok(d))) continue;
+        if (c.tile == 15 && !(rowa_enabled() && rowa_ok(d))) continue;
         if (c.tile == 16 && d.batch < 8) continue;   // measured ahead only on the per-image V^T projections (many small problems)
         const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
         long w = (blocks + cus - 1) / cus;
@@ -758,11 +988,13 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
 #ifdef LBMK_DIAG
   if (tile == 115) { launch<512, 128, 8, 2, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 117) { launch<256, 256, 4, 2, true, true, 1, false, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
 #endif
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
-  if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
-  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14 || tile == 15, "igemm: tile %d has no 64x64 wave strips", tile);
+  if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11 && tile != 18, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
+  if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14 || tile == 15 || tile == 17 || tile == 19, "igemm: tile %d has no 64x64 wave strips", tile);
   if (tile == 15) LBMK_REQUIRE(rowa_ok(d), "igemm: tile %d takes 3x3 stride-1 same-size convolutions with Cin %% 64 == 0 only", tile);
+  if (tile >= 17 && tile <= 19) LBMK_REQUIRE(pp_ok(d), "igemm: tile %d (ping-pong schedule) takes 1x1 and 3x3 stride-1 same-size layers with Cin %% 64 == 0 only", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
     case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;
@@ -782,6 +1014,9 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
     case 14: launch<128, 128, 2, 2, true, false, 2>(d, s); break;
     case 15: launch<384, 128, 6, 2, true, false, 1, true>(d, s); break;
     case 16: launch<192, 128, 4, 2, true, false, 2>(d, s); break;
+    case 17: launch<256, 256, 4, 2, true, false, 1, false, true>(d, s); break;
+    case 18: launch<256, 160, 4, 2, true, false, 1, false, true>(d, s); break;
+    case 19: launch<256, 128, 4, 2, true, false, 1, false, true>(d, s); break;
   }
   return lbmk_check_launch("igemm");
 }
