@@ -35,7 +35,7 @@ const char* lbmk_last_error(void);
 /* ------------------------------------------------------------------------
  * Implicit GEMM on bf16 MFMA:  out[m][n] = act(alpha * sum_k A(m,k) * w[n][k]
  *                                           + bias[n] + rowvec[b(m)][n] + residual[m][n])
- * A(m,k) is gathered from an NHWC tensor: m -> (b, oy, ox), k -> (kh, kw, c).
+ * A(m,k) is gathered from an NHWC tensor: m -> (b, oy, ox), k -> (kh, kw, c); KH x KW is 1x1, 2x2 or 3x3.
  * Replaces torch conv2d / linear under diffusers' UNet2DConditionModel and
  * AutoencoderKL as called from src/lbm/models/unets/unet.py:127-140 and
  * src/lbm/models/vae/autoencoderKL.py:64,116,134.  A linear layer is the
@@ -80,6 +80,16 @@ typedef struct lbmk_igemm_desc {
   int32_t in_f32;       /* fp32 mode: a, w, rowvec, residual and out are f32 (out_f32 must be 1) and the products run on
                            v_mfma_f32_32x32x2_f32 (exact f32).  Any M / N; Cin, Kp, a_cs, a_coff multiples of 4; any
                            KH x KW; k_order 0; LBMK_ACT_NONE / SILU / RELU; no gn_partial; tile is ignored            */
+  int32_t out_up2;      /* 0: output row m is pixel m.  1 + 2*py + px: pixel (b, y, x) of the OH x OW grid is written to
+                           pixel (b, 2y + py, 2x + px) of a [B][2*OH][2*OW][ldo] tensor.  A nearest-x2 upsample followed
+                           by a 3x3 / pad-1 convolution (diffusers Upsample2D, called from the decoders behind
+                           src/lbm/models/vae/autoencoderKL.py:116 and src/lbm/models/unets/unet.py:127-140) is four such
+                           2x2 convolutions of the low-resolution input, one per output parity, with the taps that fall
+                           on the same source pixel summed (pad_t = 1 - py, pad_l = 1 - px): 4/9 of the products.
+                           bf16 only; no residual                                                                   */
+  int32_t gn_nslab;     /* 0: gn_partial holds OH*OW/64 strips per (image, group).  > 0: it holds gn_nslab strips and */
+  int32_t gn_strip_off; /* this launch writes strips gn_strip_off ... gn_strip_off + OH*OW/64 - 1 (the four parity
+                           launches of one upsampling convolution share one statistics buffer)                      */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);

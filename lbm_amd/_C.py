@@ -48,6 +48,7 @@ class IgemmDesc(C.Structure):
         ("gn_partial", vp), ("gn_groups", i32),
         ("batch_inner", i32), ("sa2", i64), ("sw2", i64), ("so2", i64),
         ("in_f32", i32),
+        ("out_up2", i32), ("gn_nslab", i32), ("gn_strip_off", i32),
     ]
 
 

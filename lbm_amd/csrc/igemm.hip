@@ -74,6 +74,14 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     }
   }
 
+  // output row of GEMM row m: itself, or (out_up2) pixel (2y + py, 2x + px) of the twice-as-large output image
+  auto orow = [&](int m) -> int64_t {
+    if (!p.out_up2) return m;
+    const int b = m / ohw, r = m - b * ohw;
+    const int y = r / p.OW, x = r - y * p.OW;
+    const int par = p.out_up2 - 1;
+    return ((int64_t)(b * 2 * p.OH + 2 * y + (par >> 1)) * (2 * p.OW) + 2 * x + (par & 1));
+  };
   // output column of element 0 of column group j (GEGLU: value / gate groups alternate, j even is kept)
   auto out_col = [&](int j) { return geglu ? ((nbase + j * 16) >> 1) + lq * 4 : nbase + j * 16 + lq * 4; };
 
@@ -155,7 +163,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
           const int c = wcol(jp);
           if (row_ok && c < n_out)
-            *(u32x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            *(u32x4*)((bf16_t*)p.out + zo + orow(m) * p.ldo + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
       }
     } else {
@@ -200,13 +208,13 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           else if (p.act == LBMK_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.out_f32) {
-          float* o = (float*)p.out + zo + (int64_t)m * p.ldo + no;
+          float* o = (float*)p.out + zo + orow(m) * p.ldo + no;
           *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
         } else {
           u16x4 ov;
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
-          *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + no) = ov;
+          *(u16x4*)((bf16_t*)p.out + zo + orow(m) * p.ldo + no) = ov;
           if (gn) {   // keep the stored (rounded) value for the statistics pass below
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = bf2f(ov.v[e]);
@@ -218,7 +226,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     if (gn && mbase < p.M) {
       const int cpg = p.N / p.gn_groups;        // 4, 8 or 16 channels: whole groups inside a 16-column tile
       const int bimg = mbase / ohw;
-      const int strip = (mbase - bimg * ohw) >> 6, nslab = ohw >> 6;
+      const int strip = ((mbase - bimg * ohw) >> 6) + p.gn_strip_off, nslab = p.gn_nslab > 0 ? p.gn_nslab : ohw >> 6;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float a = 0.f, b2 = 0.f;
@@ -267,8 +275,8 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
         if (res) val += bf2f(res[(int64_t)m * p.ldr + no + e]);
         if (p.act == LBMK_ACT_SILU) val = silu_f(val);
         if (p.act == LBMK_ACT_RELU) val = fmaxf(val, 0.f);
-        if (p.out_f32) ((float*)p.out)[zo + (int64_t)m * p.ldo + no + e] = val;
-        else ((bf16_t*)p.out)[zo + (int64_t)m * p.ldo + no + e] = f2bf(val);
+        if (p.out_f32) ((float*)p.out)[zo + orow(m) * p.ldo + no + e] = val;
+        else ((bf16_t*)p.out)[zo + orow(m) * p.ldo + no + e] = f2bf(val);
       }
     }
   }
@@ -282,7 +290,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // (filter row, 64-channel chunk) pair is staged once as BM + 8 consecutive pixels of the flattened NHWC input and
 // the taps kw = 0, 1, 2 read it at row offsets 0, 1, 2: a third of the activation traffic.  Taps that fall outside
 // the image are zeroed on the fragment after the LDS read (per-lane 9-bit masks; waves without such pixels skip it).
-// PP (8 waves, Cin % 64 == 0, 1x1 or 3x3 / stride 1 / 'same' padding): ping-pong schedule.  Waves 0-3 and 4-7 (one of
+// PP (8 waves, Cin % 64 == 0, 1x1 or 2x2 / 3x3 with stride 1 and a same-size output): ping-pong schedule.  Waves 0-3 and 4-7 (one of
 // each group per SIMD) run half a K-tile apart: while one group reads its fragments of a K-tile from LDS into registers,
 // the other issues the MFMAs of the tile it read in the previous phase, so the matrix pipe of every SIMD always has one
 // wave feeding it and no wave's LDS latency is exposed.  An LDS-DMA instruction blocks its wave for on the order of a
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
         const int pix = (b - b0) * p.IH * p.IW + (ry - by0) * p.IW + rx;
         vo = (unsigned)(pix * p.a_cs + p.a_coff + (uni ? kk_ : 0)) * 2u;
         if constexpr (PP) {   // no mask register: 4 edge bits ride in the (zero) low bits of the 16-byte aligned offset
-          if (p.KW == 3) vo |= (oy == 0 ? 1u : 0u) | (oy + 1 == p.OH ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox + 1 == p.OW ? 8u : 0u);
+          if (p.KW >= 2) vo |= (oy == 0 ? 1u : 0u) | (oy + 1 == p.OH ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox + 1 == p.OW ? 8u : 0u);
         }
       } else if constexpr (PP) vo = OOB;
       a_vo[i] = vo;
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     if constexpr (FAST) {
       int kh = 0, kw = 0;
       if (p.KW == 3) { kh = (tap_s * 11) >> 5; kw = tap_s - kh * 3; }
+      else if (p.KW == 2) { kh = tap_s >> 1; kw = tap_s & 1; }
       const unsigned bit = 1u << tap_s;
       const unsigned soff = (unsigned)((p.up2 ? 0 : (kh * p.IW + kw) * p.a_cs) + chb_s) * 2u;
 #pragma unroll
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     } else {
       int kh = 0, kw = 0;
       if (p.KW == 3) { kh = (tap * 11) >> 5; kw = tap - kh * 3; }
+      else if (p.KW == 2) { kh = tap >> 1; kw = tap & 1; }
       const bool tap_ok = tap < ntaps && ch < p.Cin;
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
@@ -545,6 +555,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       kh = (tap_s * 11) >> 5;
       kw = tap_s - kh * 3;
       sel = (kh == 0 ? 1u : kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : kw == 2 ? 8u : 0u);
+    } else if (p.KW == 2) {   // rows y - pad_t, y - pad_t + 1: the first is outside on the first image row (pad_t = 1), the second on the last (pad_t = 0)
+      kh = tap_s >> 1;
+      kw = tap_s & 1;
+      sel = (kh == 0 ? (p.pad_t ? 1u : 0u) : (p.pad_t ? 0u : 2u)) | (kw == 0 ? (p.pad_l ? 4u : 0u) : (p.pad_l ? 0u : 8u));
     }
     const unsigned soff = (unsigned)((kh * p.IW + kw) * p.a_cs + chb_s) * 2u;
 #pragma unroll
@@ -852,6 +866,7 @@ inline bool pp_enabled() {
 inline bool pp_ok(const lbmk_igemm_desc& d) {
   if (d.Cin % 64) return false;
   if (d.KH == 1) return d.pad_t == 0 && d.pad_l == 0;
+  if (d.KH == 2) return d.stride == 1 && !d.up2 && (d.pad_t | 1) == 1 && (d.pad_l | 1) == 1 && d.OH == d.IH && d.OW == d.IW;
   return d.stride == 1 && !d.up2 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.IH && d.OW == d.IW;
 }
 
@@ -899,7 +914,12 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   LBMK_REQUIRE(d.a && d.w && d.out, "igemm: null operand");
   LBMK_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "igemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
   LBMK_REQUIRE(d.batch >= 1 && d.batch <= 65535, "igemm: batch %d", d.batch);
-  LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
+  LBMK_REQUIRE((d.KH == 1 && d.KW == 1) || (d.KH == 2 && d.KW == 2) || (d.KH == 3 && d.KW == 3), "igemm: kernel %dx%d", d.KH, d.KW);
+  LBMK_REQUIRE(d.out_up2 >= 0 && d.out_up2 <= 4, "igemm: out_up2 %d", d.out_up2);
+  if (d.out_up2) LBMK_REQUIRE(!d.residual && !d.out_f32 && d.batch == 1 && d.act != LBMK_ACT_GEGLU && (int64_t)d.M * 4 < (1LL << 31),
+                              "igemm: out_up2 takes an unbatched bf16 launch without residual");
+  LBMK_REQUIRE(d.gn_nslab >= 0 && d.gn_strip_off >= 0 && (d.gn_nslab == 0 ? d.gn_strip_off == 0 : d.gn_strip_off + d.OH * d.OW / 64 <= d.gn_nslab),
+               "igemm: statistics strips %d + %d of %d", d.gn_strip_off, d.OH * d.OW / 64, d.gn_nslab);
   LBMK_REQUIRE(d.Cin > 0 && d.Cin % 8 == 0, "igemm: Cin=%d must be a multiple of 8", d.Cin);
   LBMK_REQUIRE(d.K == d.KH * d.KW * d.Cin, "igemm: K=%d != KH*KW*Cin", d.K);
   LBMK_REQUIRE((int64_t)(d.N + 512) * d.Kp < (1LL << 30), "igemm: weight matrix %d x %d overflows 32-bit byte offsets", d.N, d.Kp);
@@ -994,7 +1014,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11 && tile != 18, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
   if (gn) LBMK_REQUIRE(tile == 0 || tile == 4 || tile == 7 || tile == 8 || tile == 10 || tile == 14 || tile == 15 || tile == 17 || tile == 19, "igemm: tile %d has no 64x64 wave strips", tile);
   if (tile == 15) LBMK_REQUIRE(rowa_ok(d), "igemm: tile %d takes 3x3 stride-1 same-size convolutions with Cin %% 64 == 0 only", tile);
-  if (tile >= 17 && tile <= 19) LBMK_REQUIRE(pp_ok(d), "igemm: tile %d (ping-pong schedule) takes 1x1 and 3x3 stride-1 same-size layers with Cin %% 64 == 0 only", tile);
+  if (tile >= 17 && tile <= 19) LBMK_REQUIRE(pp_ok(d), "igemm: tile %d (ping-pong schedule) takes 1x1 and 2x2 / 3x3 stride-1 same-size layers with Cin %% 64 == 0 only", tile);
   hipStream_t s = (hipStream_t)stream;
   switch (tile) {
     case 0: launch<128, 128, 2, 2, false, false, 4>(d, s); break;

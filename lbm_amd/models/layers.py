@@ -6,12 +6,18 @@ never calls torch's implementation.  Activations are bf16 channels-last ``[B, H,
 (equivalently ``[B, H*W, C]`` tokens).  Packed / converted weights are cached per layer
 and rebuilt when the parameter is modified in place, replaced, or moved.
 """
+import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
 
 from .. import ops
+
+
+# LBM_NO_UP2_SPLIT=1: upsampling convolutions gather through the upsample (3x3, 9 taps) instead of running as four 2x2
+# parity convolutions (same-box A/B runs)
+_UP2_SPLIT = os.environ.get("LBM_NO_UP2_SPLIT") is None
 
 
 def _stamp(*tensors):
@@ -45,6 +51,10 @@ class HipConv2d(nn.Conv2d, _Cached):
     def packed(self) -> ops.PackedWeight:
         return self._cached("w", (self.weight, self.bias), lambda: ops.pack_conv_weight(self.weight, self.bias))
 
+    def packed_up2(self):
+        """the four parity filters of 'nearest x2 upsample, then this 3x3 convolution' (ops.pack_conv_weight_up2)"""
+        return self._cached("u", (self.weight, self.bias), lambda: ops.pack_conv_weight_up2(self.weight, self.bias))
+
     def packed_dgrad(self) -> ops.PackedWeight:
         """input-gradient filter of a stride-1 convolution: in/out channels swapped, taps flipped"""
         return self._cached("d", (self.weight,), lambda: ops.pack_conv_weight_dgrad(self.weight))
@@ -75,6 +85,10 @@ class HipConv2d(nn.Conv2d, _Cached):
             out_hw = (x.shape[1] // 2, x.shape[2] // 2)
             return ops.conv2d(x, self.packed(), stride=s, pad=(0, 0), out_hw=out_hw, rowvec=rowvec,
                               residual=residual, act=act, gn_groups=self.gn_groups)
+        if (up2 and _UP2_SPLIT and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and rowvec is None and residual is None
+                and s == 1 and self.kernel_size == (3, 3) and self.padding[0] == 1 and self.in_channels % 64 == 0):
+            # inference, bf16: the upsampling convolution as four 2x2 convolutions of the low-resolution input
+            return ops.conv2d_up2(x, self.packed_up2(), act=act, gn_groups=self.gn_groups)
         return ops.conv2d(x, self.packed(), stride=s, pad=(self.padding[0], self.padding[1]), up2=up2,
                           rowvec=rowvec, residual=residual, act=act, gn_groups=self.gn_groups)
 

@@ -127,6 +127,62 @@ def _pack_conv_weight_dev(weight: torch.Tensor, bias: Optional[torch.Tensor], dg
     return PackedWeight(packed, b, rows_p, K, Kp, cols_p, KH, KW, alg_nk=rows * KH * KW * cols, k_order=k_order)
 
 
+def pack_conv_weight_up2(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Nearest-x2 upsample followed by a 3x3 / pad-1 convolution, as four 2x2 convolutions of the low-resolution
+    input, one per output parity (py, px).  Output row 2y + py reads upsampled rows 2y + py - 1 ... + 1, i.e. source rows
+    {y - 1, y, y} (py = 0) or {y, y, y + 1} (py = 1): the taps that land on one source pixel are summed (in f32, rounded
+    to bf16 once).  Returns [(PackedWeight, pad_t, pad_l)] in parity order 2 * py + px; each part does 4/9 of the
+    products of its quarter of the output."""
+    N, Cin, KH, KW = weight.shape
+    assert KH == 3 and KW == 3
+    w = weight.detach().float()
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}      # parity -> filter rows summed into tap 0 / tap 1
+    parts = []
+    for py in (0, 1):
+        for px in (0, 1):
+            w2 = torch.zeros(N, Cin, 2, 2, dtype=torch.float32, device=w.device)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w2[:, :, dy, dx] = w[:, :, rows[py][dy], :][:, :, :, rows[px][dx]].sum(dim=(2, 3))
+            parts.append((pack_conv_weight(w2.to(bf16).contiguous(), bias), 1 - py, 1 - px))
+    return parts
+
+
+def conv2d_up2(x: torch.Tensor, parts, *, act: int = ACT_NONE, tile: int = -1, gn_groups: int = 0) -> torch.Tensor:
+    """x: bf16 [B, H, W, C] -> [B, 2H, 2W, N]: upsample + 3x3 convolution from ``pack_conv_weight_up2`` parts.  Each
+    parity launch scatters its pixels into the shared output (lbmk_igemm_desc.out_up2) and, when ``gn_groups``, its
+    statistics strips into one partial-sum buffer for the GroupNorm that follows."""
+    pw0 = parts[0][0]
+    _need_gpu(x, pw0.w)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == bf16 and not pw0.geglu
+    B, IH, IW, Cs = x.shape
+    out = torch.empty(B, 2 * IH, 2 * IW, pw0.N, dtype=bf16, device=x.device)
+    partial = None
+    if gn_groups:
+        nfl = lib.lbmk_igemm_gn_partial_floats(4 * B * IH * IW, pw0.N, pw0.Cin, 2 * IH, 2 * IW, gn_groups)
+        if nfl > 0 and (IH * IW) % 64 == 0:
+            partial = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    for q, (pw, pad_t, pad_l) in enumerate(parts):
+        d = IgemmDesc()
+        d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), out.data_ptr()
+        d.bias = _ptr(pw.bias)
+        d.M, d.N, d.K, d.Kp = B * IH * IW, pw.N, pw.K, pw.Kp
+        d.Cin, d.a_cs, d.a_coff = pw.Cin, Cs, 0
+        d.IH, d.IW, d.OH, d.OW = IH, IW, IH, IW
+        d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 2, 2, 1, pad_t, pad_l
+        d.ldo = pw.N
+        d.act, d.alpha, d.batch = act, 1.0, 1
+        d.tile, d.k_order = tile, pw.k_order
+        d.out_up2 = 1 + q
+        if partial is not None:
+            d.gn_partial, d.gn_groups = partial.data_ptr(), gn_groups
+            d.gn_nslab, d.gn_strip_off = 4 * ((IH * IW) // 64), q * ((IH * IW) // 64)
+        _igemm(d, 2.0 * d.M * pw.alg_nk)
+    if partial is not None:
+        out._lbmk_gn_partial = (partial, gn_groups, (4 * IH * IW) // 64)
+    return out
+
+
 def pack_conv_weight_dgrad(weight: torch.Tensor) -> PackedWeight:
     """input-gradient filter of a stride-1 convolution: in/out channels swapped, taps flipped"""
     if weight.is_cuda and weight.dtype == bf16 and weight.is_contiguous():

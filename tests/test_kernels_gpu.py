@@ -380,6 +380,44 @@ def test_conv3x3_wide_tiles(ops, cuda, gen, tile):
     assert rel_l2(y2, _conv_ref(x, w, b, 1, 1, up2=True)) < 4e-3
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 7, 8, 11, 14, 17, 18, 19])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 24, 128, 256), (1, 9, 7, 64, 96), (3, 8, 8, 192, 128)])
+def test_conv_up2_as_four_parity_convolutions(ops, cuda, gen, tile, B, H, W, cin, cout):
+    """nearest x2 upsample + 3x3 convolution computed as four 2x2 convolutions of the low-resolution input (4/9 of the
+    products): against torch's upsample + conv2d in f32, and against the kernel that gathers through the upsample"""
+    x = randbf(gen, B, H, W, cin)
+    w = randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5)
+    b = randbf(gen, cout)
+    parts = ops.pack_conv_weight_up2(w.to(cuda), b.to(cuda))
+    assert [(pt, pl) for _, pt, pl in parts] == [(1, 1), (1, 0), (0, 1), (0, 0)]
+    y = ops.conv2d_up2(x.to(cuda), parts, tile=tile)
+    ref = _conv_ref(x, w, b, 1, 1, up2=True)
+    assert y.shape == (B, 2 * H, 2 * W, cout)
+    assert rel_l2(y, ref) < 4e-3
+    assert (y.float().cpu() - ref).abs().max() < 0.1
+    y9 = ops.conv2d(x.to(cuda), ops.pack_conv_weight(w.to(cuda), b.to(cuda)), up2=True)
+    assert rel_l2(y, y9.float().cpu()) < 4e-3      # summed taps are rounded to bf16 once: not the same bits
+
+
+def test_conv_up2_parity_convolutions_carry_groupnorm_stats(ops, cuda, gen):
+    B, H, W, cin, cout, G = 2, 16, 32, 128, 256, 32
+    x = randbf(gen, B, H, W, cin)
+    w = randbf(gen, cout, cin, 3, 3, scale=(9 * cin) ** -0.5)
+    b = randbf(gen, cout)
+    gam, bet = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+    parts = ops.pack_conv_weight_up2(w.to(cuda), b.to(cuda))
+    for tile in (-1, 7, 17):
+        y = ops.conv2d_up2(x.to(cuda), parts, gn_groups=G, tile=tile)
+        assert getattr(y, "_lbmk_gn_partial", None) is not None
+        y_plain = ops.conv2d_up2(x.to(cuda), parts, tile=tile)
+        assert torch.equal(y, y_plain)
+        n_fused = ops.groupnorm(y, gam.to(cuda), bet.to(cuda), G, 1e-6, True)
+        ref = F.silu(F.group_norm(y.float().cpu().permute(0, 3, 1, 2), G, gam, bet, 1e-6)).permute(0, 2, 3, 1)
+        assert rel_l2(n_fused, ref) < 4e-3
+        n_plain = ops.groupnorm(y_plain, gam.to(cuda), bet.to(cuda), G, 1e-6, True)
+        assert (n_fused.float() - n_plain.float()).abs().max() < 0.04
+
+
 def test_conv3x3_every_tile_returns_the_same_bits(ops, cuda, gen):
     """every tile shape sums a layer's products in the same order (64-channel chunks, taps inside a chunk, two 32-deep
     MFMA steps per K-tile), so the automatic choice of a tile - which depends on the batch size - cannot change a bit
