@@ -270,14 +270,17 @@ def main():
     roofline, cpu, secondary = None, None, None
     if rank == 0 and not args.no_roofline:
         # dominant kernel = the implicit-GEMM conv / linear kernel: every launch of one extra, untimed
-        # step is bracketed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch
+        # step is bracketed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch of the
+        # reference operation (an upsampling convolution counts its 9 taps although the four parity convolutions
+        # that compute it multiply 4/9 of them: "executed" is the rate of the products actually multiplied)
         ops.igemm_profile_begin()
         one_step(model, images, enc_eps, args.nfe)
         prof = ops.igemm_profile_end()
         tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args)[0],
+                    "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                    "executed": round(prof["executed"] / (prof["ms"] * 1e-3) / 1e12, 2), "traffic": pmc_traffic(args)[0],
                     "traffic_source": (f"replayed constant from {pmc_traffic(args)[1]} (separate rocprofv3 --pmc passes over "
                                        "this command; not measured in this run)") if pmc_traffic(args)[1] else None,
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),

@@ -177,7 +177,7 @@ def conv2d_up2(x: torch.Tensor, parts, *, act: int = ACT_NONE, tile: int = -1, g
         if partial is not None:
             d.gn_partial, d.gn_groups = partial.data_ptr(), gn_groups
             d.gn_nslab, d.gn_strip_off = 4 * ((IH * IW) // 64), q * ((IH * IW) // 64)
-        _igemm(d, 2.0 * d.M * pw.alg_nk)
+        _igemm(d, 2.0 * d.M * pw.alg_nk * 9 / 4, executed=2.0 * d.M * pw.alg_nk)
     if partial is not None:
         out._lbmk_gn_partial = (partial, gn_groups, (4 * IH * IW) // 64)
     return out
@@ -241,7 +241,7 @@ _profile = None   # when a dict: per-launch HIP-event timing of the implicit-GEM
 
 def igemm_profile_begin():
     global _profile
-    _profile = {"events": [], "flops": 0.0}
+    _profile = {"events": [], "flops": 0.0, "executed": 0.0}
 
 
 def igemm_profile_end() -> dict:
@@ -250,7 +250,7 @@ def igemm_profile_end() -> dict:
     p, _profile = _profile, None
     torch.cuda.synchronize()
     ms = sum(a.elapsed_time(b) for a, b in p["events"])
-    return {"ms": ms, "flops": p["flops"], "launches": len(p["events"]), "aux": aux_profile_summary(p)}
+    return {"ms": ms, "flops": p["flops"], "executed": p["executed"], "launches": len(p["events"]), "aux": aux_profile_summary(p)}
 
 
 def _timed(kind: str, work: float, launch):
@@ -274,7 +274,9 @@ def aux_profile_summary(p: dict) -> dict:
     return out
 
 
-def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None):
+def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None, executed: Optional[float] = None):
+    """alg_flops: products of the reference operation this launch stands for (un-padded shapes; an upsampling
+    convolution counts its 9 taps); executed: products the launch multiplies, when an algebraic shortcut makes that less"""
     if _profile is None:
         check(lib.lbmk_igemm(C.byref(desc), _stream()), "lbmk_igemm")
         return
@@ -286,6 +288,7 @@ def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None):
     if alg_flops is None:
         alg_flops = 2.0 * desc.M * desc.N * desc.K * desc.batch
     _profile["flops"] += alg_flops
+    _profile["executed"] += alg_flops if executed is None else executed
 
 
 def conv2d(x: torch.Tensor, pw: PackedWeight, *, stride: int = 1, pad=(1, 1), up2: bool = False,
