@@ -60,11 +60,15 @@ typedef struct lbmk_igemm_desc {
   float alpha;
   int32_t batch;        /* independent problems (grid.z); strides below in elements    */
   int64_t sa, sw, so, sr;
-  int32_t tile;         /* -1 auto, else index into the tile table (see lbmk_igemm_tiles).  Tile 15 (384x128,
-                           persistent, one staged input slab per filter row shared by its three taps) takes 3x3
-                           stride-1 pad-1 same-size convolutions with Cin % 64 == 0 and batch 1 only; auto picks it
-                           for those when 96 <= N <= 256 and M >= 65536 (environment LBMK_NO_ROWA=1: never;
-                           LBMK_NO_PERSIST=1: one workgroup per tile) */
+  int32_t tile;         /* -1 auto (a cost model over the production tiles), else index into the tile table (see
+                           lbmk_igemm_tiles).  Every tile sums a layer's products in the same order, so the choice never
+                           changes a bit of the result.  Tile 15 (384x128, persistent, one staged input slab per filter
+                           row shared by its three taps) takes 3x3 stride-1 pad-1 same-size convolutions with
+                           Cin % 64 == 0 and batch 1 only.  Tiles 17 / 18 / 19 (256x256 / 256x160 / 256x128, 8 waves in
+                           two groups that alternate between reading fragments and issuing MFMAs) take 1x1 and 2x2 / 3x3
+                           stride-1 same-size layers with Cin % 64 == 0.  Environment, read once per process, for A/B
+                           runs: LBMK_NO_ROWA=1 (never tile 15), LBMK_NO_PERSIST=1 (tile 15 with one workgroup per
+                           tile), LBMK_NO_PP=1 (never tiles 17 / 18) */
   int32_t k_order;      /* 0: k = tap*Cin + c;  1 (Cin % 64 == 0): k = (c/64)*KH*KW*64 + tap*64 + c%64,
                            i.e. the 9 taps of one 64-channel chunk are consecutive K tiles (L1 reuse) */
   float* gn_partial;    /* NULL, or GroupNorm partial sums of the (bf16-rounded) output, written by the
