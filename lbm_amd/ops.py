@@ -127,12 +127,11 @@ def _pack_conv_weight_dev(weight: torch.Tensor, bias: Optional[torch.Tensor], dg
     return PackedWeight(packed, b, rows_p, K, Kp, cols_p, KH, KW, alg_nk=rows * KH * KW * cols, k_order=k_order)
 
 
-def pack_conv_weight_up2(weight: torch.Tensor, bias: Optional[torch.Tensor]):
-    """Nearest-x2 upsample followed by a 3x3 / pad-1 convolution, as four 2x2 convolutions of the low-resolution
-    input, one per output parity (py, px).  Output row 2y + py reads upsampled rows 2y + py - 1 ... + 1, i.e. source rows
-    {y - 1, y, y} (py = 0) or {y, y, y + 1} (py = 1): the taps that land on one source pixel are summed (in f32, rounded
-    to bf16 once).  Returns [(PackedWeight, pad_t, pad_l)] in parity order 2 * py + px; each part does 4/9 of the
-    products of its quarter of the output."""
+def up2_parity_filters(weight: torch.Tensor):
+    """[N, Cin, 3, 3] -> [(w2 [N, Cin, 2, 2] f32, pad_t, pad_l)] in parity order 2 * py + px, such that
+    conv3x3(pad 1)(upsample_nearest_2x(x))[:, :, py::2, px::2] == conv2x2(pad top/left pad_t/pad_l, bottom/right
+    1 - pad)(x).  Output row 2y + py reads upsampled rows 2y + py - 1 ... + 1, i.e. source rows {y - 1, y, y} (py = 0) or
+    {y, y, y + 1} (py = 1): the taps that land on one source pixel are summed (in f32)."""
     N, Cin, KH, KW = weight.shape
     assert KH == 3 and KW == 3
     w = weight.detach().float()
@@ -144,8 +143,16 @@ def pack_conv_weight_up2(weight: torch.Tensor, bias: Optional[torch.Tensor]):
             for dy in (0, 1):
                 for dx in (0, 1):
                     w2[:, :, dy, dx] = w[:, :, rows[py][dy], :][:, :, :, rows[px][dx]].sum(dim=(2, 3))
-            parts.append((pack_conv_weight(w2.to(bf16).contiguous(), bias), 1 - py, 1 - px))
+            parts.append((w2, 1 - py, 1 - px))
     return parts
+
+
+def pack_conv_weight_up2(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Nearest-x2 upsample followed by a 3x3 / pad-1 convolution, as four 2x2 convolutions of the low-resolution
+    input, one per output parity (``up2_parity_filters``; each summed tap is rounded to bf16 once).  Returns
+    [(PackedWeight, pad_t, pad_l)] in parity order 2 * py + px; each part does 4/9 of the products of its quarter of
+    the output."""
+    return [(pack_conv_weight(w2.to(bf16).contiguous(), bias), pt, pl) for w2, pt, pl in up2_parity_filters(weight)]
 
 
 def conv2d_up2(x: torch.Tensor, parts, *, act: int = ACT_NONE, tile: int = -1, gn_groups: int = 0) -> torch.Tensor:

@@ -8,7 +8,7 @@ from lbm_amd import ops, _C
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-tiles = [int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else [-1, 0, 1, 3, 7, 8, 10, 11, 12, 13, 14]
+tiles = [int(t) for t in sys.argv[3].split(',')] if len(sys.argv) > 3 else [-1, 0, 1, 3, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, res)
 images = (torch.rand(B, 3, res, res) * 2 - 1).to(torch.bfloat16).to(dev)
@@ -18,10 +18,10 @@ torch.cuda.synchronize()
 
 seen = collections.OrderedDict()
 orig = ops._igemm
-def patched(desc, alg_flops=None):
-    orig(desc, alg_flops)
+def patched(desc, alg_flops=None, executed=None):
+    orig(desc, alg_flops, executed)
     key = (desc.M, desc.N, desc.K, desc.KH, desc.stride, desc.up2, desc.batch, desc.act, desc.out_f32, 1 if desc.gn_partial else 0,
-           desc.Cin)
+           desc.Cin, 1 if desc.residual else 0, desc.out_up2)
     if key not in seen:
         d = _C.IgemmDesc()
         ctypes.memmove(ctypes.byref(d), ctypes.byref(desc), ctypes.sizeof(d))
@@ -48,6 +48,7 @@ for key, (d, count) in seen.items():
             b.record(); torch.cuda.synchronize()
             us = a.elapsed_time(b) / 3 * 1e3
             times[t] = min(times.get(t, 1e12), us)
-    M, N, K, KH, s, up, z, act, f32, gn, cin = key
+    M, N, K, KH, s, up, z, act, f32, gn, cin, resid, oup = key
     print(json.dumps({"M": M, "N": N, "K": K, "KH": KH, "stride": s, "up2": up, "batch": z, "act": act, "f32": f32, "gn": gn, "Cin": cin,
+                      "res": resid, "out_up2": oup,
                       "count": count, "us": {str(t): round(v, 1) for t, v in times.items()}}), flush=True)

@@ -152,3 +152,23 @@ def test_shared_row_lds_swizzle_is_conflict_free_for_all_tap_shifts():
     plain = [(r >> 1) & 7 for r in range(16)]
     assert mod.conflict_free(plain, (0,)) and not mod.conflict_free(plain, (1,)) and not mod.conflict_free(plain, (2,))
     assert mod.search() == h
+
+
+def test_upsampling_convolution_is_four_parity_convolutions():
+    """the identity behind the 4/9-work upsampler (lbm_amd.ops.up2_parity_filters), in f32 on the CPU: every output
+    parity of conv3x3(upsample_nearest_2x(x)) is a 2x2 convolution of x with summed taps and one-sided padding"""
+    import torch
+    import torch.nn.functional as F
+    from lbm_amd.ops import up2_parity_filters
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 5, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 6, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    parts = up2_parity_filters(w)
+    assert [(pt, pl) for _, pt, pl in parts] == [(1, 1), (1, 0), (0, 1), (0, 0)]
+    for q, (w2, pt, pl) in enumerate(parts):
+        py, px = q >> 1, q & 1
+        xp = F.pad(x, (pl, 1 - pl, pt, 1 - pt))
+        got = F.conv2d(xp, w2.double())
+        assert got.shape == (2, 4, 5, 7)
+        assert torch.allclose(got, ref[:, :, py::2, px::2], atol=1e-5, rtol=1e-5), q

@@ -194,6 +194,21 @@ def test_gemm_nt_batched(ops, cuda, gen):
     assert rel_l2(y2, ref2) < 4e-3
 
 
+@pytest.mark.parametrize("tile", [7, 17, 18, 19])
+def test_gemm_nt_batched_on_every_wide_tile(ops, cuda, gen, tile):
+    """batched launches (grid.z, two batch levels) on the 16-wave and the ping-pong tiles: ragged M / N, several tiles
+    per problem, f32 and bf16 outputs; the same bits whichever tile runs"""
+    Z1, Z2, M, N, K = 2, 3, 300, 410, 192
+    a = randbf(gen, Z1, Z2, M, K).to(cuda)
+    b = randbf(gen, Z1, Z2, N, K).to(cuda)
+    y = ops.gemm_nt(a, b, out_dtype=torch.float32, alpha=0.25, tile=tile)
+    ref = 0.25 * torch.einsum("uzmk,uznk->uzmn", a.float().cpu(), b.float().cpu())
+    assert rel_l2(y, ref) < 1e-5
+    yb = ops.gemm_nt(a, b, tile=tile)
+    assert rel_l2(yb, 4.0 * ref) < 4e-3
+    assert torch.equal(yb, ops.gemm_nt(a, b, tile=0))
+
+
 @pytest.mark.parametrize("C,HW", [(320, 256), (1920, 64), (2560, 36), (128, 1000), (512, 144), (960, 100)])
 @pytest.mark.parametrize("silu", [False, True])
 def test_groupnorm(ops, cuda, gen, C, HW, silu):
