@@ -418,6 +418,18 @@ def test_get_model_evaluate_end_to_end(cuda, tmp_path):
     print(f"get_model/evaluate 1024x1024 (bucket of a 512x512 input): encode rel-L2 {zerr:.4f}, image PSNR {psnr:.1f} dB")
     assert zerr < 1e-2
     assert psnr >= 40.0
+    # BASELINE config 3 at full size: 4-step sampling at 1024x1024 (the noise drawn after steps 0..2 injected on both
+    # sides); LBMModel.sample returns the decoded image
+    eps4 = [torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(60 + i)).to(BF) for i in range(3)]
+    with torch.no_grad():
+        img4 = model.sample(seen["z"], num_steps=4, eps_list=[e.to(cuda) for e in eps4]).clamp(-1, 1).float().cpu()
+        lat4_ref = br.sample(z_ref, lambda s_, t: dr.unet_forward(usd, cfg, s_, t), 4, [e.float() for e in eps4], 0.005)
+        img4_ref = dr.vae_decode(vsd, lat4_ref / 0.13025).clamp(-1, 1)
+    assert img4.shape == img4_ref.shape == (1, 3, 1024, 1024)
+    mse4 = float(((img4 - img4_ref) ** 2).mean()) / 4.0
+    psnr4 = 10 * math.log10(1.0 / max(mse4, 1e-12))
+    print(f"4-step sampling 1024x1024: image PSNR {psnr4:.1f} dB against the fp32 oracle")
+    assert psnr4 >= 40.0
     # the same checkpoint in fp32 mode (BASELINE config 1 is an fp32 configuration): get_model(torch_dtype=float32)
     del model
     torch.cuda.empty_cache()
