@@ -285,6 +285,14 @@ int lbmk_gemm_tn(const void* a, const void* b, void* out, int M, int N, int K, i
  * summed in a fixed order) -> bf16 (out_dtype 0) or f32 (1).  Part of the dW = dY^T X path above. */
 int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream);
 
+/* Finish of a split-K linear layer of the training step (torch.nn.functional.linear forward / input gradient under the
+ * reference's trainer, src/lbm/trainer/trainer.py:60-90, on the few-row token matrices of a 512x512 batch): the K
+ * range is cut into nseg chunks that run as ONE batched lbmk_igemm launch with f32 outputs part[s][M][N] (chunk s reads
+ * channels s*K/nseg ... of a and columns s*K/nseg ... of w: sa = sw = K/nseg, so = seg_stride), and this kernel writes
+ * out[m][n] = bf16(sum_s part[s][m][n] + bias[n] + residual[m][n]), chunks added in order.  N % 8 == 0. */
+int lbmk_splitk_finish(const float* part, int nseg, int64_t seg_stride, const float* bias, const void* residual,
+                       int ldr, void* out, int ldo, int M, int N, void* stream);
+
 /* out[g][n] = sum of x[m][n] over the rows_per_group consecutive rows of group g (bias gradient: one group;
  * time-embedding gradient: one group per image).  x bf16 [rows][ld]; out bf16 (0) / f32 (1) [rows/rows_per_group][N] */
 int64_t lbmk_colsum_scratch_floats(int64_t rows, int64_t rows_per_group, int N);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "lbmk_colsum_scratch_floats": (i64, [i64, i64, i32]),
     "lbmk_colsum": (i32, [vp, vp, vp, i64, i64, i32, i64, i32, vp]),
     "lbmk_sum_partials": (i32, [vp, vp, i64, i32, i32, vp]),
+    "lbmk_splitk_finish": (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i32, i32, vp]),
     "lbmk_gemm_tn": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_lpips_prep": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

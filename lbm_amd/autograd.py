@@ -36,12 +36,32 @@ def _grad_sink(param):
     return ent if ent is not None and ent.active else None
 
 
+def _linear_maybe_splitk(x, pw, residual):
+    """the few-row, deep-K linear layers of a training step as a split-K launch (ops.splitk_chunks); None = not eligible"""
+    if x.dtype != bf16 or pw.geglu or pw.KH != 1 or pw.w.dtype != bf16 or pw.N % 8:
+        return None
+    x2 = _rows(x)
+    if x2.stride(1) != 1 or x2.shape[1] != pw.K:
+        return None
+    S = ops.splitk_chunks(x2.shape[0], pw.N, pw.K)
+    if not S:
+        return None
+    r2 = None
+    if residual is not None:
+        r2 = _rows(residual)
+        if r2.dtype != bf16 or r2.stride(1) != 1 or r2.shape != (x2.shape[0], pw.N):
+            return None
+    return ops.linear_splitk(x2, pw, S, r2).reshape(*x.shape[:-1], pw.N)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ W^T + b (+ residual) (+ rowvec[image]); ``mod`` supplies the cached packed weights."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, rowvec, mod, rows_per_image):
-        y = ops.linear(x, mod.packed(), residual=residual, rowvec=rowvec, rows_per_image=rows_per_image)
+        y = _linear_maybe_splitk(x, mod.packed(), residual) if rowvec is None else None
+        if y is None:
+            y = ops.linear(x, mod.packed(), residual=residual, rowvec=rowvec, rows_per_image=rows_per_image)
         ctx.save_for_backward(x, weight)
         ctx.mod, ctx.has_bias, ctx.rows_per_image = mod, bias is not None, rows_per_image
         ctx.has_res, ctx.has_rv = residual is not None, rowvec is not None
@@ -55,7 +75,10 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape
         dx = dw = db = dres = drv = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy2, ctx.mod.packed_t())[:, :K].reshape(x.shape)
+            dx = _linear_maybe_splitk(dy2, ctx.mod.packed_t(), None)
+            if dx is None:
+                dx = ops.linear(dy2, ctx.mod.packed_t())
+            dx = dx[:, :K].reshape(x.shape)
         if ctx.needs_input_grad[1]:
             xc = x2.contiguous() if x2.stride(1) != 1 else x2
             sink = _grad_sink(ctx.mod.weight)

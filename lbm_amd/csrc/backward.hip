@@ -259,7 +259,46 @@ __global__ __launch_bounds__(256) void sum_partials_vec_kernel(const float* __re
     *(u16x4*)((bf16_t*)out + i * 4) = o;
   }
 }
+// split-K forward / input-gradient GEMM: out[m][n] = bf16(sum_s part[s][m][n] + bias[n] + residual[m][n]), 8 columns per thread
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int nseg, int64_t seg_stride,
+                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            int ldr, bf16_t* __restrict__ out, int ldo, int M, int n8) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * n8) return;
+  const int m = (int)(i / n8), c = (int)(i - (int64_t)m * n8) * 8;
+  const int N = n8 * 8;
+  const float* p0 = part + (int64_t)m * N + c;
+  f32x4 a0 = *(const f32x4*)p0, a1 = *(const f32x4*)(p0 + 4);
+  for (int s = 1; s < nseg; ++s) {
+    a0 += *(const f32x4*)(p0 + s * seg_stride);
+    a1 += *(const f32x4*)(p0 + s * seg_stride + 4);
+  }
+  if (bias) { a0 += *(const f32x4*)(bias + c); a1 += *(const f32x4*)(bias + c + 4); }
+  u16x8 o;
+  if (res) {
+    const u16x8 r = *(const u16x8*)(res + (int64_t)m * ldr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a0[e] += bf2f(r.v[e]); a1[e] += bf2f(r.v[4 + e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o.v[e] = f2bf(a0[e]); o.v[4 + e] = f2bf(a1[e]); }
+  *(u16x8*)(out + (int64_t)m * ldo + c) = o;
+}
 }  // namespace
+
+extern "C" int lbmk_splitk_finish(const float* part, int nseg, int64_t seg_stride, const float* bias, const void* residual,
+                                  int ldr, void* out, int ldo, int M, int N, void* stream) {
+  LBMK_REQUIRE(part && out && nseg >= 1 && M > 0 && N > 0 && N % 8 == 0, "splitk_finish: nseg=%d M=%d N=%d", nseg, M, N);
+  LBMK_REQUIRE(seg_stride >= (int64_t)M * N && seg_stride % 4 == 0 && ldo >= N && ldo % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)),
+               "splitk_finish: strides");
+  LBMK_REQUIRE(lbmk_aligned(part, 16) && lbmk_aligned(out, 16) && (!residual || lbmk_aligned(residual, 16)) && (!bias || lbmk_aligned(bias, 16)),
+               "splitk_finish: 16-byte alignment");
+  const int64_t n = (int64_t)M * (N / 8);
+  LBMK_REQUIRE((n + 255) / 256 < (1LL << 31), "splitk_finish: grid");
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, nseg, seg_stride,
+                     bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N / 8);
+  return lbmk_check_launch("splitk_finish");
+}
 
 extern "C" int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream) {
   LBMK_REQUIRE(partial && out && n > 0 && nseg > 0, "sum_partials: n=%lld nseg=%d", (long long)n, nseg);

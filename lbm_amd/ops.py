@@ -6,6 +6,7 @@ current HIP stream to liblbmk.  Activations are bf16 channels-last: a ``[B, H, W
 tensor (contiguous) which is at the same time the ``[B*H*W, C]`` token matrix.
 """
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -418,6 +419,50 @@ def linear(x: torch.Tensor, pw: PackedWeight, *, residual: Optional[torch.Tensor
     d.batch, d.sa, d.sw, d.so, d.sr = 1, 0, 0, 0, 0
     d.tile = tile
     _igemm(d, 2.0 * d.M * pw.alg_nk if pw.alg_nk else None)
+    return out
+
+
+_SPLITK = os.environ.get("LBM_NO_SPLITK") is None      # LBM_NO_SPLITK=1: same-box A/B runs
+
+
+def splitk_chunks(M: int, N: int, K: int) -> int:
+    """K chunks for a few-row linear layer (0: one launch).  Measured on MI355X: a batched launch over K chunks plus
+    the finishing pass wins only when the output is too small to fill the chip (M <= 2048 rows, N <= 2560 columns)
+    and K is deep (>= 3840); everywhere else it loses.  The summation order differs from the single launch, so only
+    the training path (whose tile choice is not pinned to batch invariance) uses it."""
+    if M > 2048 or N > 2560 or K < 3840 or not _SPLITK:
+        return 0
+    for S in (4, 2):
+        if K % (S * 64) == 0:
+            return S
+    return 0
+
+
+def linear_splitk(x: torch.Tensor, pw: PackedWeight, S: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: bf16 [M, K] (unit column stride) -> bf16 [M, N] = x @ W^T + bias (+ residual): S K-chunks as one batched
+    implicit-GEMM launch with f32 partial outputs, then lbmk_splitk_finish."""
+    _need_gpu(x, pw.w)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == bf16 and not pw.geglu and pw.KH == 1
+    M, K = x.shape
+    assert K == pw.K and K % (S * 64) == 0 and pw.N % 8 == 0
+    Kc, N = K // S, pw.N
+    part = torch.empty(S, M, N, dtype=torch.float32, device=x.device)
+    d = IgemmDesc()
+    d.a, d.w, d.out = x.data_ptr(), pw.w.data_ptr(), part.data_ptr()
+    d.M, d.N, d.K, d.Kp = M, N, Kc, pw.Kp
+    d.Cin, d.a_cs, d.a_coff = Kc, x.stride(0), 0
+    d.IH = d.IW = d.OH = d.OW = 1
+    d.KH = d.KW = d.stride = 1
+    d.ldo, d.out_f32, d.alpha, d.act = N, 1, 1.0, ACT_NONE
+    d.batch, d.sa, d.sw, d.so = S, Kc, Kc, M * N
+    d.tile = -1
+    _igemm(d, 2.0 * M * pw.alg_nk if pw.alg_nk else None)
+    out = torch.empty(M, N, dtype=bf16, device=x.device)
+    if residual is not None:
+        assert residual.dtype == bf16 and residual.shape == (M, N) and residual.stride(1) == 1
+    check(lib.lbmk_splitk_finish(part.data_ptr(), S, M * N, _ptr(pw.bias), _ptr(residual),
+                                 residual.stride(0) if residual is not None else 0, out.data_ptr(), N, M, N, _stream()),
+          "lbmk_splitk_finish")
     return out
 
 

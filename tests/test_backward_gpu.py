@@ -38,9 +38,12 @@ def test_transpose_colsum(cuda, gen):
     assert rel_l2(s4, x.float().reshape(4, 34, 72).sum(1)) < 4e-3
 
 
-@pytest.mark.parametrize("M,K,N", [(300 * 8, 320, 640), (16, 1280, 320), (4096, 64, 72)])
+# the last two take the split-K route (few rows, deep K) in the forward GEMM / in the input-gradient GEMM
+@pytest.mark.parametrize("M,K,N", [(300 * 8, 320, 640), (16, 1280, 320), (4096, 64, 72), (520, 3840, 328), (264, 320, 4096)])
 def test_linear_backward(cuda, gen, M, K, N):
+    from lbm_amd import ops
     from lbm_amd.models.layers import HipLinear
+    assert bool(ops.splitk_chunks(M, N, K)) == (K >= 3840) and bool(ops.splitk_chunks(M, K, N)) == (N >= 3840)
     lin = HipLinear(K, N).to(BF)
     with torch.no_grad():
         lin.weight.copy_(randbf(gen, N, K, scale=K ** -0.5))
