@@ -154,7 +154,7 @@ class GroupNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps, silu):
-        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        g32, b32 = ops.f32_of(weight), ops.f32_of(bias)
         y, stats = ops.groupnorm_train(x, g32, b32, groups, eps, silu)
         ctx.save_for_backward(x, stats, g32, b32)
         ctx.cfg = (groups, silu, weight.dtype)
@@ -171,7 +171,7 @@ class GroupNormFn(torch.autograd.Function):
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
-        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        g32, b32 = ops.f32_of(weight), ops.f32_of(bias)
         y = ops.layernorm(x, g32, b32, eps)
         ctx.save_for_backward(x, g32)
         ctx.cfg = (eps, weight.dtype)

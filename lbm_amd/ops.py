@@ -73,6 +73,16 @@ class PackedWeight:
     k_order: int = 0                # 1: K runs chunk-major (64 channels x all taps), see lbmk_igemm_desc.k_order
 
 
+def f32_of(p: torch.Tensor) -> torch.Tensor:
+    """contiguous f32 copy of a (bias / norm) parameter.  The trainer keeps f32 shadows of all 1-D parameters, refreshed
+    by one multi-tensor copy after each optimizer step (HipAdamW.invalidate) and stamped with the parameter's version;
+    a current shadow is returned as is, anything else is converted here."""
+    ent = getattr(p, "_lbmk_f32", None)
+    if ent is not None and ent[1] == p._version and ent[0].device == p.device:
+        return ent[0]
+    return p.detach().float().contiguous()
+
+
 def pack_conv_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedWeight:
     """[Cout, Cin, KH, KW] -> bf16 [Cout_p, Kp] with k = (kh*KW + kw)*Cin_p + c.
     Both channel counts are padded to multiples of 8 with zeros, so every channels-last
@@ -123,8 +133,11 @@ def _pack_conv_weight_dev(weight: torch.Tensor, bias: Optional[torch.Tensor], dg
                                     1 if dgrad else 0, _stream()), "lbmk_pack_conv_weight")
     b = None
     if bias is not None:
-        b = torch.zeros(rows_p, dtype=torch.float32, device=weight.device)
-        b[:rows] = bias.detach().float()
+        if rows_p == rows:
+            b = f32_of(bias)
+        else:
+            b = torch.zeros(rows_p, dtype=torch.float32, device=weight.device)
+            b[:rows] = bias.detach().float()
     return PackedWeight(packed, b, rows_p, K, Kp, cols_p, KH, KW, alg_nk=rows * KH * KW * cols, k_order=k_order)
 
 
@@ -202,7 +215,7 @@ def pack_linear_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Pa
     """[N, K] -> bf16 [N, Kp] (K padded to a multiple of 64 with zeros)."""
     N, K = weight.shape
     k8 = ceil_to(K, 8)
-    b = None if bias is None else bias.detach().float().contiguous()
+    b = None if bias is None else f32_of(bias)
     w = weight.detach()
     if w.dtype == torch.float32:
         # fp32 mode: the f32 parameter itself when its rows are 16-byte multiples

@@ -345,6 +345,7 @@ class HipAdamW:
         self.groups, self.betas, self.eps, self.weight_decay = groups, tuple(betas), eps, weight_decay
         self.rank, self.sharded = rank, sharded
         self.step_count = 0
+        self._small = None          # 1-D parameters and their f32 shadows (built at the first invalidate)
         self.param_groups = [{"params": g.params, "lr": g.lr} for g in groups]
         for g in groups:
             n = g.numel // g.shards if sharded else g.numel
@@ -372,10 +373,20 @@ class HipAdamW:
                                eps=self.eps, weight_decay=self.weight_decay, step=self.step_count, grad_scale=grad_scale)
 
     def invalidate(self):
-        """the kernel (and the all-gather) wrote parameters through raw pointers: invalidate cached weight packs"""
+        """the kernel (and the all-gather) wrote parameters through raw pointers: invalidate cached weight packs, and
+        refresh the f32 shadows of the 1-D parameters (biases, norm scales / shifts: ops.f32_of) with one multi-tensor
+        copy instead of one conversion kernel per parameter and use"""
         for g in self.groups:
             for p in g.params:
                 torch.autograd.graph.increment_version(p)
+        if self._small is None:
+            self._small = [] if os.environ.get("LBM_NO_F32_SHADOW") else [p for g in self.groups for p in g.params if p.dim() == 1 and p.dtype != torch.float32]
+            self._small32 = [torch.empty(p.shape, dtype=torch.float32, device=p.device) for p in self._small]
+        if self._small:
+            with torch.no_grad():
+                torch._foreach_copy_(self._small32, [p.detach() for p in self._small])
+            for p, sh in zip(self._small, self._small32):
+                p._lbmk_f32 = (sh, p._version)
 
     def zero_grad(self, set_to_none: bool = False):
         for g in self.groups:
