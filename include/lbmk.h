@@ -103,7 +103,7 @@ int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int 
 int lbmk_igemm_tiles(int* bm, int* bn, int cap);
 #ifdef LBMK_DIAG
 /* Diagnostic builds only (make -C lbm_amd/csrc DIAG=1; absent from the product library; no reference counterpart):
- * tile ids 115 / 116 run the 512x128 / 256x256 tiles with in-kernel time stamps; this copies out 8 x uint64 per
+ * tile ids 115 / 116 / 117 run the 512x128 / 256x256 16-wave tiles and the 256x256 ping-pong tile with in-kernel time stamps; this copies out 8 x uint64 per
  * workgroup (100 MHz wall-clock stamps at start, after set-up, first stage landed, K loop done, epilogue issued, stores
  * drained; shader-clock counter at the K loop's start and end), nblocks <= 65536.  The one entry point that
  * synchronises the device.  Returns the hipError_t of the copy. */

@@ -16,7 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-// Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116) record six 100 MHz
+// Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116 / 117) record six 100 MHz
 // wall-clock stamps per workgroup: start, after set-up, first stage landed, K loop done, epilogue
 // issued, stores drained; slots 6 / 7 hold the shader-clock counter at the start / end of the K loop
 // (in-kernel clock = delta(6..7) / delta(2..3) * 100 MHz).  lbmk_debug_igemm_times() copies them out.
