@@ -94,9 +94,21 @@ typedef struct lbmk_igemm_desc {
   int32_t gn_nslab;     /* 0: gn_partial holds OH*OW/64 strips per (image, group).  > 0: it holds gn_nslab strips and */
   int32_t gn_strip_off; /* this launch writes strips gn_strip_off ... gn_strip_off + OH*OW/64 - 1 (the four parity
                            launches of one upsampling convolution share one statistics buffer)                      */
+  int32_t smx_mode;     /* 0: off.  Two-pass row softmax over a scores GEMM (the single-head, head_dim-512 attention of the
+                           VAE mid block, src/lbm/models/vae/autoencoderKL.py:64,116: torch SDPA there), without
+                           ever storing the f32 scores: pass 1 writes only row maxima, pass 2 multiplies again and stores
+                           the exponentials as bf16.
+                           1: no output tile; smx_part[z][m][strip] = max over the strip's columns of alpha * acc.
+                           2: out[m][n] = bf16(exp2(alpha * acc - smx_max[z][m])); smx_part[z][m][strip] = sum of the
+                              stored values.  lbmk_igemm_smx_parts(N) strips per row (64 columns each; a strip wholly
+                              past N holds -inf in pass 1 and 0 in pass 2): reduce over all of them.  1x1, K % 64 == 0,
+                              no bias / residual / activation                                                     */
+  const float* smx_max; /* pass 2: f32 [batch][M] row maxima (same alpha as pass 1)                               */
+  float* smx_part;      /* f32 [batch][M][lbmk_igemm_smx_parts(N)]                                                */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
+int lbmk_igemm_smx_parts(int N);
 /* floats behind gn_partial for a descriptor's shape, or -1 when the shape cannot carry fused statistics */
 int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int gn_groups);
 /* number of tile configurations; cfg i has block tile bm[i] x bn[i] */

@@ -282,6 +282,43 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
   }
 }
 
+// Epilogues of the two-pass row softmax over a scores GEMM (attention with a head too wide for the fused kernel):
+// SMX = 1 writes, per row and per 64-column wave strip, the maximum of alpha * acc (no tile is stored);
+// SMX = 2 stores p = exp2(alpha * acc - smx_max[row]) as bf16 and the strip's sum of the stored (rounded) values.
+// Partial index: strip = tile_n * WAVES_N + wn of `parts` strips per row; columns past N take no part.
+template <int MI, int NI, int SMX>
+__device__ __forceinline__ void igemm_epilogue_smx(const lbmk_igemm_desc& p, f32x4 (&acc)[MI][NI], int mbase, int nbase,
+                                                   int lane, int64_t zo, int z, int strip, int parts) {
+  const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mbase + i * 16 + lr;
+    const bool row_ok = m < p.M;
+    const int64_t row = (int64_t)z * p.M + (row_ok ? m : 0);
+    const float mx = (SMX == 2) ? p.smx_max[row] : 0.f;
+    float red = SMX == 1 ? -INFINITY : 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = nbase + j * 16 + lq * 4;
+      u16x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = col + e < p.N;
+        const float sv = acc[i][j][e] * p.alpha;
+        if (SMX == 1) red = ok ? fmaxf(red, sv) : red;
+        else {
+          ov.v[e] = f2bf(ok ? __builtin_amdgcn_exp2f(sv - mx) : 0.f);
+          red += bf2f(ov.v[e]);
+        }
+      }
+      if (SMX == 2 && row_ok && col < p.N) *(u16x4*)((bf16_t*)p.out + zo + (int64_t)m * p.ldo + col) = ov;
+    }
+    if (SMX == 1) { red = fmaxf(red, __shfl_xor(red, 16, 64)); red = fmaxf(red, __shfl_xor(red, 32, 64)); }
+    else { red += __shfl_xor(red, 16, 64); red += __shfl_xor(red, 32, 64); }
+    if (lq == 0 && row_ok) p.smx_part[row * parts + strip] = red;
+  }
+}
+
 // FAST: Cin % 64 == 0 -- every lane of a K-tile is on the same filter tap, so the
 // tap / channel walk is scalar and a load costs three vector ALU instructions.
 // OCC: workgroups meant to share a CU (caps the register budget at 512 / (OCC * waves per SIMD)).
@@ -297,7 +334,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 // hundred cycles, so every wave issues its loads in its READ phase only, behind its fragment reads.  For that to meet the
 // landing deadlines the activation tile has two stage buffers whose halves are staged by the group that does not read
 // them, and the weight tile (read by both groups) has three.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false, bool ROWA = false, bool PP = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DBUF, bool FAST, bool STAMP = false, int OCC = 1, bool GNS = false, bool ROWA = false, bool PP = false, int SMX = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 3) / 4) void igemm_kernel(const lbmk_igemm_desc p) {
   constexpr int NW = WAVES_M * WAVES_N;         // waves per workgroup (4 or 8)
   constexpr int NT = 64 * NW;
@@ -817,6 +854,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
 
   DBG_C(7);
   DBG_T(3);
+  if constexpr (SMX != 0) {
+    igemm_epilogue_smx<MI, NI, SMX>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, zo, (int)blockIdx.z, (n0 / BN) * WAVES_N + wn,
+                                    tiles_n * WAVES_N);
+    return;
+  }
   igemm_epilogue<MI, NI, GNS>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, zo, zr);
   if (STAMP) { DBG_T(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DBG_T(5); }
 }
@@ -900,6 +942,8 @@ extern "C" int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, i
   return (int64_t)(M / 64) * G * 2;
 }
 
+extern "C" int lbmk_igemm_smx_parts(int N) { return N > 0 ? ((N + 255) / 256) * 4 : -1; }
+
 extern "C" int lbmk_igemm_tiles(int* bm, int* bn, int cap) {
   for (int i = 0; i < kNumTiles && i < cap; ++i) { bm[i] = kTiles[i].bm; bn[i] = kTiles[i].bn; }
   return kNumTiles;
@@ -960,6 +1004,21 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
                  "igemm: gn statistics need 16-byte aligned output / residual rows");
   }
 
+  if (d.smx_mode) {
+    // two-pass row softmax over a scores GEMM: the 16-wave 256x256 tile with the reducing epilogues
+    LBMK_REQUIRE(d.smx_mode == 1 || d.smx_mode == 2, "igemm: smx_mode %d", d.smx_mode);
+    LBMK_REQUIRE(fast_path(d) && d.KH == 1 && !gn && !d.bias && !d.residual && !d.rowvec && d.act == LBMK_ACT_NONE && !d.out_up2,
+                 "igemm: the softmax passes take a plain 1x1 GEMM with K %% 64 == 0");
+    LBMK_REQUIRE(d.smx_part && lbmk_aligned(d.smx_part, 4) && (d.smx_mode == 1 || (d.smx_max && !d.out_f32 && d.N % 4 == 0 && d.ldo % 4 == 0)),
+                 "igemm: softmax pass %d operands", d.smx_mode);
+    const int tm = (d.M + 255) / 256, tn = (d.N + 255) / 256;
+    dim3 grid((unsigned)(tm * tn), 1, (unsigned)d.batch);
+    if (d.smx_mode == 1)
+      hipLaunchKernelGGL((igemm_kernel<256, 256, 4, 4, true, true, false, 1, false, false, false, 1>), grid, dim3(1024), 0, (hipStream_t)stream, d);
+    else
+      hipLaunchKernelGGL((igemm_kernel<256, 256, 4, 4, true, true, false, 1, false, false, false, 2>), grid, dim3(1024), 0, (hipStream_t)stream, d);
+    return lbmk_check_launch("igemm");
+  }
   int tile = d.tile;
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;

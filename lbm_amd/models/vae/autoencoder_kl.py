@@ -27,6 +27,10 @@ _SCORE_BYTES_BUDGET = 2 << 30   # f32 score matrices materialised at once by the
 FLASH_HEAD_DIMS = (8, 16, 32, 40, 64, 80, 160)
 
 
+# LBM_NO_TWO_PASS_ATTN=1: the unfused path with f32 scores (same-box A/B runs)
+_TWO_PASS = os.environ.get("LBM_NO_TWO_PASS_ATTN") is None
+
+
 class VaeAttention(nn.Module, _Cached):
     """Self-attention over a feature map with residual (diffusers' deprecated attention block: group_norm,
     to_q / to_k / to_v with bias, to_out.0).  The VAE mid block uses one head of C = 512; UNetMidBlock2D of
@@ -68,8 +72,15 @@ class VaeAttention(nn.Module, _Cached):
         wv, bv = self._v_weight()
         vt = ops.gemm_nt(wv, xn, bias_m=bv)                     # [B, C, N]
         o = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
-        nb = max(1, min(B, _SCORE_BYTES_BUDGET // (N * N * 4)))
         scale = 1.0 / math.sqrt(C)
+        if _TWO_PASS and C % 64 == 0:
+            # bf16 probabilities only (2 bytes per score resident): chunks of images under the same budget
+            nb = max(1, min(B, _SCORE_BYTES_BUDGET // (N * N * 2)))
+            for b0 in range(0, B, nb):
+                b1 = min(B, b0 + nb)
+                o[b0:b1] = ops.attention_two_pass(q[b0:b1], k[b0:b1], vt[b0:b1], scale)
+            return self.to_out[0](o, residual=x.view(B, N, C)).view(B, H, W, C)
+        nb = max(1, min(B, _SCORE_BYTES_BUDGET // (N * N * 4)))
         for b0 in range(0, B, nb):
             b1 = min(B, b0 + nb)
             s = ops.gemm_nt(q[b0:b1], k[b0:b1], out_dtype=torch.float32, alpha=scale)   # [nb, N, N] f32

@@ -481,7 +481,8 @@ def linear_splitk(x: torch.Tensor, pw: PackedWeight, S: int, residual: Optional[
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 1.0,
             bias_m: Optional[torch.Tensor] = None, bias_n: Optional[torch.Tensor] = None,
-            residual: Optional[torch.Tensor] = None, tile: int = -1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            residual: Optional[torch.Tensor] = None, tile: int = -1, out: Optional[torch.Tensor] = None,
+            smx=None) -> torch.Tensor:
     """Batched out[z] = alpha * a[z] @ b[z]^T.  a: bf16 [M, K], [Z, M, K] or [Z1, Z2, M, K]; b likewise with N
     rows; unit stride along K, every other stride free (multiples of 8), so per-head views of a
     [B, N, H*D] tensor batch over (image, head) in one launch.  K a multiple of 8.
@@ -502,7 +503,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
     else:
         assert b.shape[-1] == K and K % 8 == 0 and b.stride(-2) % 8 == 0 and a.stride(-2) % 8 == 0
     shape = lead + (M, N)
-    if out is None:
+    if smx is not None and smx[0] == 1:
+        out = a          # pass 1 of the two-pass softmax stores no tile: any valid pointer
+    elif out is None:
         out = torch.empty(*shape, dtype=out_dtype, device=a.device)
     else:
         assert tuple(out.shape) == shape and out.stride(-1) == 1 and out.is_cuda
@@ -537,8 +540,41 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
         d.so = out.stride(0) if nb == 1 else 0
     d.sr = residual.stride(0) if (residual is not None and residual.dim() == 3) else 0
     d.tile = tile
+    if smx is not None:
+        mode, rowmax, part = smx
+        assert part.dtype == torch.float32 and part.is_contiguous() and part.numel() == max(d.batch, 1) * M * smx_parts(N)
+        d.smx_mode, d.smx_part = mode, part.data_ptr()
+        if mode == 1:
+            d.ldo, d.so, d.so2 = N, 0, 0     # nothing is stored
+        if mode == 2:
+            assert rowmax.dtype == torch.float32 and rowmax.is_contiguous() and rowmax.numel() == max(d.batch, 1) * M
+            d.smx_max = rowmax.data_ptr()
     _igemm(d)
     return out
+
+
+def smx_parts(N: int) -> int:
+    """64-column strips per row of the two-pass softmax partials"""
+    return lib.lbmk_igemm_smx_parts(N)
+
+
+def attention_two_pass(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(scale * q k^T) v for ONE wide head (the VAE mid block: head_dim 512), q / k bf16 [B, N, C], vt bf16
+    [B, C, N] -> bf16 [B, N, C].  The scores GEMM runs twice: pass 1 keeps only the row maxima, pass 2 stores
+    p = exp(s - max) as bf16 plus row sums; then P V in f32 and one normalising pass.  The f32 N x N score matrix of
+    the unfused path (12 bytes of traffic per score over its three kernels) is never written: 4 bytes per score."""
+    B, N, C = q.shape
+    assert q.dtype == bf16 and k.shape == q.shape and vt.shape == (B, C, N) and N % 8 == 0
+    alpha = scale * 1.4426950408889634       # exp2 domain
+    parts = smx_parts(N)
+    part = torch.empty(B, N, parts, dtype=torch.float32, device=q.device)
+    gemm_nt(q, k, alpha=alpha, smx=(1, None, part))
+    rowmax = part.amax(dim=-1)               # strips past N hold -inf (pass 1) / 0 (pass 2)
+    p = torch.empty(B, N, N, dtype=bf16, device=q.device)
+    gemm_nt(q, k, alpha=alpha, out=p, smx=(2, rowmax, part))
+    inv = part.sum(dim=-1).reciprocal_()
+    o = gemm_nt(p, vt, out_dtype=torch.float32)
+    return (o * inv.unsqueeze(-1)).to(bf16)
 
 
 # --------------------------------------------------------------------------------------

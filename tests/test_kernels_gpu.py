@@ -562,3 +562,27 @@ def test_pack_conv_weight_kernel_matches_host_packing(ops, cuda, gen, N, Cin, k)
     devd = ops.pack_conv_weight_dgrad(w.to(cuda))
     assert (devd.N, devd.K, devd.Kp, devd.Cin, devd.k_order, devd.alg_nk) == (refd.N, refd.K, refd.Kp, refd.Cin, refd.k_order, refd.alg_nk)
     assert torch.equal(devd.w.cpu(), refd.w)
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 1024, 512), (1, 328, 128), (3, 200, 64)])
+def test_attention_two_pass(ops, cuda, gen, B, N, C):
+    """single wide head: scores GEMM twice (row maxima, then bf16 exponentials + row sums), P V, normalise - against
+    softmax(q k^T / sqrt(C)) v in f32, and against the unfused path with f32 scores"""
+    q = randbf(gen, B, N, C)
+    k = randbf(gen, B, N, C)
+    v = randbf(gen, B, N, C)
+    scale = C ** -0.5
+    ref = torch.softmax(torch.einsum("bnc,bmc->bnm", q.float(), k.float()) * scale, -1) @ v.float()
+    vt = v.transpose(1, 2).contiguous().to(cuda)
+    o = ops.attention_two_pass(q.to(cuda), k.to(cuda), vt, scale)
+    assert o.shape == (B, N, C) and o.dtype == BF
+    assert rel_l2(o, ref) < 6e-3
+    s = ops.gemm_nt(q.to(cuda), k.to(cuda), out_dtype=torch.float32, alpha=scale)
+    o1 = ops.gemm_nt(ops.softmax_rows(s), vt)
+    assert rel_l2(o, o1.float().cpu()) < 6e-3
+    # a row with one dominant key: the maximum's own exponential is exactly 1
+    qq = q.clone()
+    qq[0, 5] = (k[0, 17].float() * 4).to(BF)
+    o2 = ops.attention_two_pass(qq.to(cuda), k.to(cuda), vt, scale)
+    ref2 = torch.softmax(torch.einsum("bnc,bmc->bnm", qq.float(), k.float()) * scale, -1) @ v.float()
+    assert torch.isfinite(o2.float()).all() and rel_l2(o2, ref2) < 6e-3
