@@ -35,6 +35,63 @@ __device__ unsigned long long igemm_dbg[65536 * 8];
 
 __device__ __forceinline__ bool lbmk_aligned_dev(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
+// (image, row, column) of flattened output pixel m.  Image sizes that are powers of two (the shipped models at
+// power-of-two resolutions, and every linear layer: one "pixel" per image) take shifts; the general case divides,
+// ~25 vector instructions per quotient, which is what a tile's set-up and epilogue were spending their issue slots on.
+struct PixelIndex {
+  int ohw, ow, sh_ohw, sh_ow;
+  bool pow2;
+  __device__ __forceinline__ PixelIndex(int oh, int ow_) : ohw(oh * ow_), ow(ow_) {
+    pow2 = (ohw & (ohw - 1)) == 0 && (ow & (ow - 1)) == 0;
+    sh_ohw = __builtin_ctz(ohw);
+    sh_ow = __builtin_ctz(ow);
+  }
+  __device__ __forceinline__ int image(int m) const { return pow2 ? m >> sh_ohw : m / ohw; }
+  __device__ __forceinline__ void operator()(int m, int& b, int& oy, int& ox) const {
+    if (pow2) {
+      b = m >> sh_ohw;
+      const int r = m & (ohw - 1);
+      oy = r >> sh_ow;
+      ox = r & (ow - 1);
+    } else {
+      b = m / ohw;
+      const int r = m - b * ohw;
+      oy = r / ow;
+      ox = r - oy * ow;
+    }
+  }
+};
+
+// v + (v of lane ^ 1) + ... summed as the xor butterfly over a 16-lane row sums it, on the vector ALU's lane
+// permutes: quad swaps for ^ 1 and ^ 2; then mirrors inside 8 and 16 lanes, which pair every lane with a lane of the
+// other quad / other half -- all lanes of a quad (half) hold the same partial sum by then and x + y == y + x, so the
+// bits equal the butterfly's.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xb1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4e>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
+// v + (v of lane ^ 16) / (v of lane ^ 32): the row swaps leave one register with the even rows' (low half's) values
+// on every lane and one with the odd rows' (high half's)
+__device__ __forceinline__ float xor16_sum(float v) {
+  // (the builtin returns one register for both halves when its operands hold the same value)
+  unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  // (the builtin returns one register for both halves when its operands hold the same value)
+  unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
+}
+
 // Epilogue shared by every tile shape: acc[i][j] is the 16x16 tile (i, j) of this wave, whose first
 // output row / packed column are mbase / nbase.
 // Loads are batched ahead of the stores on purpose: `out` may alias anything as far as the compiler
@@ -45,6 +102,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
                                                int nbase, int lane, int64_t zo, int64_t zr) {
   const int lr = lane & 15, lq = lane >> 4;
   const int ohw = p.OH * p.OW;
+  const PixelIndex pix(p.OH, p.OW);
   const bf16_t* __restrict__ res = p.residual ? (const bf16_t*)p.residual + zr : nullptr;
   const bf16_t* __restrict__ rowvec = (const bf16_t*)p.rowvec;
   const float* __restrict__ bias = p.bias;
@@ -56,13 +114,24 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
   // fold alpha and the bias into the accumulators in place (the bias registers die right here)
   {
     float bv[NI][4];
+    const bool bias_n = bias && !p.bias_per_m;
+    if (bias_n && (p.N & 3) == 0 && lbmk_aligned_dev(bias, 16)) {   // one 16-byte load per column group
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j) {
+        const int n = nbase + j * 16 + lq * 4;
+        const f32x4 b4 = n < p.N ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = nbase + j * 16 + lq * 4 + e;
-        bv[j][e] = (bias && !p.bias_per_m && n < p.N) ? bias[n] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[j][e] = b4[e];
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = nbase + j * 16 + lq * 4 + e;
+          bv[j][e] = (bias_n && n < p.N) ? bias[n] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mbase + i * 16 + lr;
@@ -77,8 +146,8 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
   // output row of GEMM row m: itself, or (out_up2) pixel (2y + py, 2x + px) of the twice-as-large output image
   auto orow = [&](int m) -> int64_t {
     if (!p.out_up2) return m;
-    const int b = m / ohw, r = m - b * ohw;
-    const int y = r / p.OW, x = r - y * p.OW;
+    int b, y, x;
+    pix(m, b, y, x);
     const int par = p.out_up2 - 1;
     return ((int64_t)(b * 2 * p.OH + 2 * y + (par >> 1)) * (2 * p.OW) + 2 * x + (par & 1));
   };
@@ -108,7 +177,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
       auto fetchw = [&](int i) {
         const int m = mbase + i * 16 + lr;
         const bool row_ok = m < p.M;
-        const int bimg = (rowvec && row_ok) ? m / ohw : 0;
+        const int bimg = (rowvec && row_ok) ? pix.image(m) : 0;
 #pragma unroll
         for (int jp = 0; jp < NI / 2; ++jp) {
           const int c = wcol(jp);
@@ -141,6 +210,20 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
         }
         const int m = mbase + i * 16 + lr;
         const bool row_ok = m < p.M;
+        // the activation as one uniform branch per row group (written per element, every element gets its own
+        // scalar compare-and-branch pair and the epilogue is bound by instruction issue, not by its stores)
+        if (p.act == LBMK_ACT_SILU) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = silu_f(acc[i][j][e]);
+        } else if (p.act == LBMK_ACT_RELU) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+        }
+        bf16_t* const orow_p = (bf16_t*)p.out + zo + orow(m) * p.ldo;
 #pragma unroll
         for (int jp = 0; jp < NI / 2; ++jp) {
           unsigned pk[2][2];
@@ -150,10 +233,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
             bf16_t o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float v = acc[i][j][e];
-              if (p.act == LBMK_ACT_SILU) v = silu_f(v);
-              else if (p.act == LBMK_ACT_RELU) v = fmaxf(v, 0.f);
-              o[e] = f2bf(v);
+              o[e] = f2bf(acc[i][j][e]);
               if (gn) acc[i][j][e] = bf2f(o[e]);   // keep the stored (rounded) value for the statistics pass below
             }
             pk[jj][0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
@@ -162,8 +242,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
           const int c = wcol(jp);
-          if (row_ok && c < n_out)
-            *(u32x4*)((bf16_t*)p.out + zo + orow(m) * p.ldo + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          if (row_ok && c < n_out) *(u32x4*)(orow_p + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
       }
     } else {
@@ -171,7 +250,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     auto fetch = [&](int i) {
       const int m = mbase + i * 16 + lr;
       const bool row_ok = m < p.M;
-      const int bimg = (rowvec && row_ok) ? m / ohw : 0;
+      const int bimg = (rowvec && row_ok) ? pix.image(m) : 0;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int no = out_col(j);
@@ -194,27 +273,41 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
       }
       const int m = mbase + i * 16 + lr;
       if (m >= p.M) continue;
+      // activation: one uniform branch per row group (per element it costs a scalar compare-and-branch pair each)
+      if (geglu) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if (geglu && (j & 1)) continue;
-        const int no = out_col(j);
-        if (no >= n_out) continue;
-        float v[4];
+        for (int j = 0; j + 1 < NI; j += 2)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][j][e];
-          if (geglu) v[e] *= gelu_erf_f(acc[i][(j + 1) % NI][e]);
-          else if (p.act == LBMK_ACT_SILU) v[e] = silu_f(v[e]);
-          else if (p.act == LBMK_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) acc[i][j][e] *= gelu_erf_f(acc[i][j + 1][e]);
+      } else if (p.act == LBMK_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = silu_f(acc[i][j][e]);
+      } else if (p.act == LBMK_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+      }
+      const int64_t orow_off = zo + orow(m) * p.ldo;
+      if (p.out_f32) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (geglu && (j & 1)) continue;
+          const int no = out_col(j);
+          if (no < n_out) *(f32x4*)((float*)p.out + orow_off + no) = acc[i][j];
         }
-        if (p.out_f32) {
-          float* o = (float*)p.out + zo + orow(m) * p.ldo + no;
-          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (geglu && (j & 1)) continue;
+          const int no = out_col(j);
+          if (no >= n_out) continue;
           u16x4 ov;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(v[e]);
-          *(u16x4*)((bf16_t*)p.out + zo + orow(m) * p.ldo + no) = ov;
+          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(acc[i][j][e]);
+          *(u16x4*)((bf16_t*)p.out + orow_off + no) = ov;
           if (gn) {   // keep the stored (rounded) value for the statistics pass below
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = bf2f(ov.v[e]);
@@ -225,7 +318,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     }
     if (gn && mbase < p.M) {
       const int cpg = p.N / p.gn_groups;        // 4, 8 or 16 channels: whole groups inside a 16-column tile
-      const int bimg = mbase / ohw;
+      const int bimg = pix.image(mbase);
       const int strip = ((mbase - bimg * ohw) >> 6) + p.gn_strip_off, nslab = p.gn_nslab > 0 ? p.gn_nslab : ohw >> 6;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -237,13 +330,12 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
             for (int e = 0; e < 4; ++e) { a += acc[i][j][e]; b2 += acc[i][j][e] * acc[i][j][e]; }
           }
         }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {   // over the 16 rows held by lanes of equal lq
-          a += __shfl_xor(a, off, 64);
-          b2 += __shfl_xor(b2, off, 64);
-        }
-        if (cpg >= 8) { a += __shfl_xor(a, 16, 64); b2 += __shfl_xor(b2, 16, 64); }
-        if (cpg == 16) { a += __shfl_xor(a, 32, 64); b2 += __shfl_xor(b2, 32, 64); }
+        // over the 16 rows held by lanes of equal lq, then over lq: the butterfly lane ^ 1, 2, 4, 8, 16, 32 without the
+        // LDS crossbar (a ds_bpermute and its wait per step made this section as long as the stores)
+        a = row16_sum(a);
+        b2 = row16_sum(b2);
+        if (cpg >= 8) { a = xor16_sum(a); b2 = xor16_sum(b2); }
+        if (cpg == 16) { a = xor32_sum(a); b2 = xor32_sum(b2); }
         const int col = nbase + j * 16 + lq * 4;
         const bool writer = lr == 0 && col < p.N && (cpg == 4 || (cpg == 8 && !(lq & 1)) || (cpg == 16 && lq == 0));
         if (writer) {
@@ -261,7 +353,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
   for (int i = 0; i < MI; ++i) {
     const int m = mbase + i * 16 + lr;
     if (m >= p.M) continue;
-    const int bimg = rowvec ? m / ohw : 0;
+    const int bimg = rowvec ? pix.image(m) : 0;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if (geglu && (j & 1)) continue;
@@ -390,6 +482,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   const int sgrp = PP ? (wave >> 2) : 0;        // PP: waves 0-3 stage activation rows BM / 2 ..., waves 4-7 rows 0 ...
   const int kk = (slot ^ ((rsub >> 1) & 7)) * 8;   // swizzled k offset inside the 64-wide tile
   const int ohw = p.OH * p.OW;
+  const PixelIndex pix(p.OH, p.OW);
   const int IHe = p.up2 ? 2 * p.IH : p.IH;
   const int IWe = p.up2 ? 2 * p.IW : p.IW;
   const int ntaps = p.KH * p.KW;
@@ -410,13 +503,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
   auto tile_setup = [&]() __attribute__((always_inline)) {
     const int rs = rsub, kk_ = kk;
     // descriptor base: first input row any tap of this tile's first output row can touch
-    const int b0 = m0 / ohw;
-    const int oy0 = (m0 - b0 * ohw) / p.OW;
+    int b0, oy0, ox0_;
+    pix(m0, b0, oy0, ox0_);
     int by0 = oy0 * p.stride - p.pad_t;
     by0 = by0 < 0 ? 0 : by0;
     if (p.up2) by0 >>= 1;
     const int64_t base_pix = (int64_t)b0 * p.IH * p.IW + (int64_t)by0 * p.IW;
-    int64_t rem = ((int64_t)(p.M / ohw) * p.IH * p.IW - base_pix) * p.a_cs * 2;
+    int64_t rem = ((int64_t)pix.image(p.M) * p.IH * p.IW - base_pix) * p.a_cs * 2;
     rem = rem > 0x7fffffff ? 0x7fffffff : rem;
     a_base = A + base_pix * p.a_cs;
     a_bytes = (int)rem;
@@ -425,8 +518,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       const int m = m0 + rs + RPP * i + (PP ? (1 - sgrp) * (BM / 2) : 0);
       unsigned mask = 0, vo = 0;
       if (m < p.M) {
-        const int b = m / ohw, r2 = m - b * ohw;
-        const int oy = r2 / p.OW, ox = r2 - oy * p.OW;
+        int b, oy, ox;
+        pix(m, b, oy, ox);
         const int by = oy * p.stride - p.pad_t, bx = ox * p.stride - p.pad_l;
         unsigned mx = 0, my = 0;   // taps inside the image along x / y; mask = their outer product
 #pragma unroll
@@ -480,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
     const int kkA = (slot ^ gsw) * 8;
     const int64_t first = (int64_t)m0 - p.IW - 1;
     const int64_t base_pix = first < 0 ? 0 : first;
-    int64_t rem = ((int64_t)(p.M / ohw) * p.IH * p.IW - base_pix) * p.a_cs * 2;
+    int64_t rem = ((int64_t)pix.image(p.M) * p.IH * p.IW - base_pix) * p.a_cs * 2;
     rem = rem > 0x7fffffff ? 0x7fffffff : rem;
     a_base = A + base_pix * p.a_cs;
     a_bytes = (int)rem;
@@ -499,8 +592,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       const int m = m0 + wm * WM + i * 16 + (lane & 15);
       unsigned e = 0;     // rows past M are never stored
       if (m < p.M) {
-        const int b = m / ohw, r2 = m - b * ohw;
-        const int oy = r2 / p.OW, ox = r2 - oy * p.OW;
+        int b, oy, ox;
+        pix(m, b, oy, ox);
         e = (oy == 0 ? 1u : 0u) | (oy + 1 == p.OH ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox + 1 == p.OW ? 8u : 0u);
       }
       edge |= e << (4 * i);

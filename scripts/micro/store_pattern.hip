@@ -44,5 +44,14 @@ int main() {
   run(store_kernel<64>, "16 rows x 64 B per instr");
   run(store_kernel<128>, "8 rows x 128 B per instr");
   run(store_kernel<256>, "4 rows x 256 B per instr");
+  // Is the floor per CU or chip-wide?  The same 128 KB per workgroup with only `g` workgroups (one per CU) launched.
+  for (int g : {256, 128, 64, 32, 8}) {
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(store_kernel<64>, dim3(g), dim3(512), 0, 0, out, M, N, tiles_n);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(store_kernel<64>, dim3(g), dim3(512), 0, 0, out + (size_t)i * g * 65536, M, N, tiles_n);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
+    printf("%3d workgroups x 128 KB: %6.2f us per launch (launch overhead included), %5.2f TB/s\n", g, ms * 1e3, (double)g * 131072 / ms / 1e9);
+  }
   return 0;
 }
