@@ -33,6 +33,8 @@ __device__ unsigned long long igemm_dbg[65536 * 8];
 #endif
 
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
 __device__ __forceinline__ bool lbmk_aligned_dev(const void* p, unsigned a) { return ((uintptr_t)p & (a - 1)) == 0; }
 
 // (image, row, column) of flattened output pixel m.  Image sizes that are powers of two (the shipped models at
@@ -168,6 +170,15 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     const bool wide = (GNS && NI % 2 == 0) ||
                       ((NI % 2 == 0) && !geglu && !p.out_f32 && (n_out & 7) == 0 && (p.ldo & 7) == 0 && (zo & 7) == 0 &&
                        lbmk_aligned_dev(p.out, 16) && (!res || ((p.ldr & 7) == 0 && (zr & 7) == 0 && lbmk_aligned_dev(p.residual, 16))));
+    // statistics of the STORED (rounded) values, two per packed dword: sum and sum of squares on the bf16 dot product
+    float gsum[NI], gsq[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) gsum[j] = gsq[j] = 0.f;
+    auto gn_add = [&](int j, unsigned packed) __attribute__((always_inline)) {
+      const bf16x2_t v = __builtin_bit_cast(bf16x2_t, packed);
+      gsum[j] = __builtin_amdgcn_fdot2_f32_bf16(v, __builtin_bit_cast(bf16x2_t, 0x3f803f80u), gsum[j], false);
+      gsq[j] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gsq[j], false);
+    };
     if (wide) {
       constexpr int NP2 = NI / 2 > 0 ? NI / 2 : 1;
       u32x4 rw[NP2];
@@ -232,12 +243,10 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
             const int j = 2 * jp + jj;
             bf16_t o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = f2bf(acc[i][j][e]);
-              if (gn) acc[i][j][e] = bf2f(o[e]);   // keep the stored (rounded) value for the statistics pass below
-            }
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e]);
             pk[jj][0] = (unsigned)o[0] | ((unsigned)o[1] << 16);
             pk[jj][1] = (unsigned)o[2] | ((unsigned)o[3] << 16);
+            if (gn) { gn_add(j, pk[jj][0]); gn_add(j, pk[jj][1]); }
           }
           const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -308,9 +317,9 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
 #pragma unroll
           for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(acc[i][j][e]);
           *(u16x4*)((bf16_t*)p.out + orow_off + no) = ov;
-          if (gn) {   // keep the stored (rounded) value for the statistics pass below
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = bf2f(ov.v[e]);
+          if (gn) {
+            gn_add(j, (unsigned)ov.v[0] | ((unsigned)ov.v[1] << 16));
+            gn_add(j, (unsigned)ov.v[2] | ((unsigned)ov.v[3] << 16));
           }
         }
       }
@@ -322,14 +331,8 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
       const int strip = ((mbase - bimg * ohw) >> 6) + p.gn_strip_off, nslab = p.gn_nslab > 0 ? p.gn_nslab : ohw >> 6;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        float a = 0.f, b2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (mbase + i * 16 + lr < p.M) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a += acc[i][j][e]; b2 += acc[i][j][e] * acc[i][j][e]; }
-          }
-        }
+        // every row of the strip is a pixel: M is a multiple of 64 whenever statistics are reduced (host check)
+        float a = gsum[j], b2 = gsq[j];
         // over the 16 rows held by lanes of equal lq, then over lq: the butterfly lane ^ 1, 2, 4, 8, 16, 32 without the
         // LDS crossbar (a ds_bpermute and its wait per step made this section as long as the stores)
         a = row16_sum(a);
