@@ -117,7 +117,9 @@ int lbmk_igemm_tiles(int* bm, int* bn, int cap);
 /* Diagnostic builds only (make -C lbm_amd/csrc DIAG=1; absent from the product library; no reference counterpart):
  * tile ids 115 / 116 / 117 run the 512x128 / 256x256 16-wave tiles and the 256x256 ping-pong tile with in-kernel time stamps; this copies out 8 x uint64 per
  * workgroup (100 MHz wall-clock stamps at start, after set-up, first stage landed, K loop done, epilogue issued, stores
- * drained; shader-clock counter at the K loop's start and end), nblocks <= 65536.  The one entry point that
+ * drained; shader-clock counter at the K loop's start and end), nblocks <= 65536.  Tile id 118 runs the shared-row
+ * 384x128 tile and stamps the shader clock around the parts of one steady-state K-step instead (slots 0 ... 4: step
+ * start, requests issued, MFMAs issued, own requests landed, barrier passed).  The one entry point that
  * synchronises the device.  Returns the hipError_t of the copy. */
 int lbmk_debug_igemm_times(unsigned long long* host, int nblocks);
 #endif

@@ -16,7 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-// Diagnostic builds of the 16-wave tiles (STAMP = true, tile ids 115 / 116 / 117) record six 100 MHz
+// Diagnostic builds of the wide tiles (STAMP = true, tile ids 115 ... 118) record six 100 MHz
 // wall-clock stamps per workgroup: start, after set-up, first stage landed, K loop done, epilogue
 // issued, stores drained; slots 6 / 7 hold the shader-clock counter at the start / end of the K loop
 // (in-kernel clock = delta(6..7) / delta(2..3) * 100 MHz).  lbmk_debug_igemm_times() copies them out.
@@ -801,12 +801,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
       const bool has_next = g + 1 < ng;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
+        // diagnostic tile 118: shader-clock stamps 0 ... 4 around the parts of one steady-state K-step of the first tile
+        const bool dbg = STAMP && g == 2 && kw == 0 && vblock == (int)blockIdx.x;
+        if (dbg) DBG_C(0);
         if (kw < 2) stage_w(kh * 3 + kw + 1, chb, wnext);
         else if (has_next) stage_w(nkh * 3, nchb, wnext);
         if (has_next) {
 #pragma unroll
           for (int pc = kw; pc <= AI; pc += 3) stage_a(pc, nkh, nchb, anext);
         }
+        if (dbg) DBG_C(1);
         // read offsets are recomputed every step from one register: hoisted out of the loop, the per-tap addresses
         // of the three unrolled steps are spilled, and their scratch reloads wait on the LDS-DMA counter
         unsigned gp = gpack;
@@ -814,8 +818,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N * OCC + 
         const int gsw = (int)(gp >> (4 * kw)) & 7;
         const unsigned sel = (kh == 0 ? 1u : kh == 2 ? 2u : 0u) | (kw == 0 ? 4u : kw == 2 ? 8u : 0u);
         compute_at(acur + rdA + kw * 128, wcur + rowB, (lq ^ gsw) << 4, ((4 + lq) ^ gsw) << 4, sel & wave_edge);
+        if (dbg) DBG_C(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dbg) DBG_C(3);
         __syncthreads();
+        if (dbg) DBG_C(4);
         char* tw = wcur; wcur = wnext; wnext = tw;
       }
       char* ta = acur; acur = anext; anext = ta;
@@ -1118,7 +1125,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   int tile = d.tile;
   if (tile < 0) {
     if (d.act != LBMK_ACT_GEGLU && d.N <= 16) tile = 2;
-    else if (rowa_enabled() && rowa_ok(d) && d.N >= 96 && d.N <= 256 && d.M >= 65536) tile = 15;   // measured 3-11 % ahead of tiles 7 / 8 / 10 on these
+    else if (rowa_enabled() && rowa_ok(d) && d.N >= 96 && d.N <= 128 && d.M >= 65536) tile = 15;   // measured 6-20 % ahead of every other tile on these
     else {
       // Cost model over the production tiles: time of the busiest CU.  A CU holding w workgroups of a
       // tile runs them `resident` at a time; a round of n co-resident workgroups costs a fixed part
@@ -1128,17 +1135,17 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       // least-squares fits to measured GEMMs, M 1k..16k, N 320..10k, K 640..5k; padded rows / columns
       // are paid in full.
       struct Cand { int tile, bm, bn, resident; bool dbuf; float a, o, tc, L; };
-      static const Cand cands[] = {{7, 256, 256, 1, true, 0.f, 13.7f, 1.01f, 1.20f},  {11, 256, 160, 1, true, 0.f, 10.1f, 1.02f, 1.05f},
-                                   {8, 512, 128, 1, true, 0.f, 13.7f, 1.14f, 1.20f},  {10, 256, 128, 2, false, 0.f, 8.3f, 0.87f, 0.38f},
+      static const Cand cands[] = {{7, 256, 256, 1, true, 0.f, 12.1f, 1.01f, 1.20f},  {11, 256, 160, 1, true, 0.f, 9.0f, 1.02f, 1.05f},
+                                   {8, 512, 128, 1, true, 0.f, 12.1f, 1.14f, 1.20f},  {10, 256, 128, 2, false, 0.f, 8.3f, 0.87f, 0.38f},
                                    {0, 128, 128, 4, false, 2.8f, 4.8f, 0.55f, 0.34f}, {1, 128, 64, 4, false, 5.0f, 1.9f, 0.34f, 0.23f},
                                    {3, 64, 64, 8, false, 2.5f, 2.2f, 0.25f, 0.30f},   {12, 128, 64, 3, true, 1.9f, 4.5f, 0.34f, 0.55f},
                                    {13, 64, 64, 4, true, 3.3f, 2.0f, 0.24f, 0.42f},   {14, 128, 128, 2, true, 0.f, 7.9f, 0.20f, 0.84f},
                                    {16, 192, 128, 2, true, 0.f, 12.0f, 0.58f, 0.90f},    // offered to batched launches only (below)
                                    // ping-pong tiles: about 8 % less time per K step than their 16-wave counterparts (in-kernel
-                                   // stamps: 1.29 vs 1.41 us at 256x256), a longer epilogue (8 waves store the tile)
-                                   {17, 256, 256, 1, true, 0.f, 16.7f, 1.01f, 1.10f},  {18, 256, 160, 1, true, 0.f, 12.0f, 1.02f, 0.99f},
-                                   // shared activation rows, one persistent workgroup per CU (3x3 stride-1 convolutions)
-                                   {15, 384, 128, 1, true, 0.f, 7.9f, 1.0f, 1.0f}};
+                                   // stamps: 1.29 vs 1.41 us at 256x256), a slightly longer epilogue (8 waves store the tile)
+                                   {17, 256, 256, 1, true, 0.f, 12.8f, 1.01f, 1.10f},  {18, 256, 160, 1, true, 0.f, 9.0f, 1.02f, 0.99f},
+                                   // shared activation rows, one persistent workgroup per CU (3x3 stride-1 convolutions up to 256 columns)
+                                   {15, 384, 128, 1, true, 0.f, 8.1f, 1.48f, 1.48f}};
       const int cus = lbmk_num_cus();
       const int nkt = (d.K + 63) / 64;
       double best = 1e300;
@@ -1146,9 +1153,8 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       for (const Cand& c : cands) {
         if (gn && !(c.tile == 0 || c.tile == 7 || c.tile == 8 || c.tile == 10 || c.tile == 14 || c.tile == 15 || c.tile == 17)) continue;   // statistics strips are 64 rows per wave, column groups in pairs
         if (d.act == LBMK_ACT_GEGLU && (c.tile == 11 || c.tile == 18)) continue;   // odd number of column groups per wave
-        if (d.act == LBMK_ACT_GEGLU && c.tile == 17) continue;              // measured behind tile 7: 8 waves run the GELU epilogue of 16
         if ((c.tile == 17 || c.tile == 18) && !(pp_enabled() && pp_ok(d))) continue;
-        if (c.tile == 15 && !(rowa_enabled() && rowa_ok(d))) continue;
+        if (c.tile == 15 && !(rowa_enabled() && rowa_ok(d) && d.N <= 256)) continue;   // wider layers: the weight tile dominates its staging, 5-25 % behind
         if (c.tile == 16 && d.batch < 8) continue;   // measured ahead only on the per-image V^T projections (many small problems)
         const long blocks = (long)((d.M + c.bm - 1) / c.bm) * ((d.N + c.bn - 1) / c.bn) * d.batch;
         long w = (blocks + cus - 1) / cus;
@@ -1164,6 +1170,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
   if (tile == 115) { launch<512, 128, 8, 2, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 116) { launch<256, 256, 4, 4, true, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
   if (tile == 117) { launch<256, 256, 4, 2, true, true, 1, false, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
+  if (tile == 118) { launch<384, 128, 6, 2, true, true, 1, true>(d, (hipStream_t)stream); return lbmk_check_launch("igemm"); }
 #endif
   LBMK_REQUIRE(tile >= 0 && tile < kNumTiles, "igemm: tile %d", tile);
   if (d.act == LBMK_ACT_GEGLU) LBMK_REQUIRE(tile != 2 && tile != 11 && tile != 18, "igemm: GEGLU needs an even number (>= 2) of 16-column groups per wave");
