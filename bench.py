@@ -86,7 +86,7 @@ def cpu_baseline(model, threads):
                       f"~{n / dt * 5.33 / 23.25:.3f} images/s extrapolated by FLOPs)"}
 
 
-PMC_TRAFFIC_FILES = ("profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
+PMC_TRAFFIC_FILES = ("profiles/r02_pmc_igemm_step_traffic_v2.json", "profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
 
 
 def pmc_traffic(args):
