@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
       }
     }
     if (kv0 + KB > Nk) {   // mask the keys past the end (wave-uniform branch)
+      // the empty asm keeps this a branch: without it the compiler turns the body into 32 compare / select pairs
+      // that run for EVERY tile (a quarter of the loop's vector instructions)
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
       }
     }
     if (kv0 + KB > Nk) {
+      asm volatile("" ::: "memory");   // keeps the tail mask a branch (see flash_fwd_d64_kernel)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
