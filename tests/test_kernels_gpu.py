@@ -56,6 +56,35 @@ def test_linear(ops, cuda, gen, tile, M, N, K):
     assert rel_l2(y, ref) < 4e-3
 
 
+def test_bias_load_forms_and_image_index_forms_agree(ops, cuda, gen):
+    """The epilogue reads the bias with 16-byte loads when its pointer allows and element by element otherwise, and
+    decomposes pixel indices with shifts for power-of-two image sizes and divisions otherwise: same results."""
+    import dataclasses
+    M, N, K = 600, 320, 256
+    x = randbf(gen, M, K).to(cuda)
+    w = randbf(gen, N, K, scale=K ** -0.5)
+    b = randbf(gen, N)
+    pw = ops.pack_linear_weight(w.to(cuda), b.to(cuda))
+    big = torch.zeros(N + 8, dtype=torch.float32, device=cuda)
+    big[1:N + 1] = pw.bias
+    pw_odd = dataclasses.replace(pw, bias=big[1:N + 1])        # 4-byte aligned only
+    assert pw.bias.data_ptr() % 16 == 0 and pw_odd.bias.data_ptr() % 16 == 4
+    for tile in (-1, 0, 7, 11, 17, 18):
+        assert torch.equal(ops.linear(x, pw, tile=tile), ops.linear(x, pw_odd, tile=tile)), tile
+    # 3x3 convolution with a per-image row vector on a 24 x 40 image (divisions) against the fp32 reference;
+    # the power-of-two sizes of the other tests take the shift form
+    B, H, W, C, Nc = 2, 24, 40, 64, 64
+    xi = randbf(gen, B, H, W, C)
+    wc = randbf(gen, Nc, C, 3, 3, scale=(9 * C) ** -0.5)
+    bc = randbf(gen, Nc)
+    rv = randbf(gen, B, Nc)
+    pc = ops.pack_conv_weight(wc.to(cuda), bc.to(cuda))
+    ref = F.conv2d(xi.float().permute(0, 3, 1, 2), wc.float(), bc.float(), padding=1) + rv.float()[:, :, None, None]
+    for tile in (-1, 0, 7, 15, 17):
+        y = ops.conv2d(xi.to(cuda), pc, rowvec=rv.to(cuda), tile=tile)
+        assert rel_l2(y.float().permute(0, 3, 1, 2), ref) < 4e-3, tile
+
+
 def test_linear_small_n_tile(ops, cuda, gen):
     x = randbf(gen, 700, 320)
     w = randbf(gen, 4, 320, scale=320 ** -0.5)
