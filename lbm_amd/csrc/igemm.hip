@@ -161,14 +161,14 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
     // GroupNorm partial sums of this wave's 64-row strip (bf16-rounded values, as a separate
     // statistics pass over the stored tensor would read them)
     constexpr bool gn = GNS && MI == 4;   // separate instantiation: the 8 extra accumulators do not fit the plain kernels' budget
-    // Wide form (bf16 output, 16-byte aligned rows, an even number of column groups): lanes l and l ^ 16 hold
+    // Wide form (bf16 output, 16-byte aligned rows; an odd last column group keeps its 8-byte accesses): lanes l and l ^ 16 hold
     // channels 4 lq ... + 3 of the same pixel for every column group.  v_permlane16_swap between the packed values of
     // groups j and j + 1 leaves the even-lq lane with 8 consecutive channels of group j and the odd-lq lane with 8 of
     // group j + 1, so a store is 16 bytes per lane and 64 contiguous bytes per pixel: half the store instructions.
     // The residual is read the same way and swapped back into the accumulator layout.
     // (instantiations that reduce GroupNorm statistics take the wide form only: the host checks its conditions)
     const bool wide = (GNS && NI % 2 == 0) ||
-                      ((NI % 2 == 0) && !geglu && !p.out_f32 && (n_out & 7) == 0 && (p.ldo & 7) == 0 && (zo & 7) == 0 &&
+                      ((NI >= 2) && !geglu && !p.out_f32 && (n_out & 7) == 0 && (p.ldo & 7) == 0 && (zo & 7) == 0 &&
                        lbmk_aligned_dev(p.out, 16) && (!res || ((p.ldr & 7) == 0 && (zr & 7) == 0 && lbmk_aligned_dev(p.residual, 16))));
     // statistics of the STORED (rounded) values, two per packed dword: sum and sum of squares on the bf16 dot product
     float gsum[NI], gsq[NI];
@@ -183,6 +183,7 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
       constexpr int NP2 = NI / 2 > 0 ? NI / 2 : 1;
       u32x4 rw[NP2];
       u16x4 rv[NI];
+      u16x4 rlast = {{0, 0, 0, 0}};   // residual of an odd last column group
       // first channel of this lane's 16-byte segment of column-group pair jp
       auto wcol = [&](int jp) { return nbase + (2 * jp + (lq & 1)) * 16 + (lq & 2) * 4; };
       auto fetchw = [&](int i) {
@@ -193,6 +194,10 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
         for (int jp = 0; jp < NI / 2; ++jp) {
           const int c = wcol(jp);
           rw[jp] = (res && row_ok && c < n_out) ? *(const u32x4*)(res + (int64_t)m * p.ldr + c) : u32x4{0u, 0u, 0u, 0u};
+        }
+        if constexpr (NI & 1) {
+          const int no = out_col(NI - 1);
+          rlast = (res && row_ok && no < n_out) ? *(const u16x4*)(res + (int64_t)m * p.ldr + no) : u16x4{{0, 0, 0, 0}};
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -216,6 +221,10 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
                 const unsigned w = ra[jj][e >> 1];
                 acc[i][2 * jp + jj][e] += __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16)) + bf2f(rv[2 * jp + jj].v[e]);
               }
+          }
+          if constexpr (NI & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][NI - 1][e] += bf2f(rlast.v[e]) + bf2f(rv[NI - 1].v[e]);
           }
           if (i + 1 < MI) fetchw(i + 1);
         }
@@ -252,6 +261,13 @@ __device__ __forceinline__ void igemm_epilogue(const lbmk_igemm_desc& p, f32x4 (
           const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
           const int c = wcol(jp);
           if (row_ok && c < n_out) *(u32x4*)(orow_p + c) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+        if constexpr (NI & 1) {
+          const int no = out_col(NI - 1);
+          u16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov.v[e] = f2bf(acc[i][NI - 1][e]);
+          if (row_ok && no < n_out) *(u16x4*)(orow_p + no) = ov;
         }
       }
     } else {
@@ -1135,7 +1151,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
       // least-squares fits to measured GEMMs, M 1k..16k, N 320..10k, K 640..5k; padded rows / columns
       // are paid in full.
       struct Cand { int tile, bm, bn, resident; bool dbuf; float a, o, tc, L; };
-      static const Cand cands[] = {{7, 256, 256, 1, true, 0.f, 12.1f, 1.01f, 1.20f},  {11, 256, 160, 1, true, 0.f, 9.0f, 1.02f, 1.05f},
+      static const Cand cands[] = {{7, 256, 256, 1, true, 0.f, 12.1f, 1.01f, 1.20f},  {11, 256, 160, 1, true, 0.f, 8.0f, 1.02f, 1.05f},
                                    {8, 512, 128, 1, true, 0.f, 12.1f, 1.14f, 1.20f},  {10, 256, 128, 2, false, 0.f, 8.3f, 0.87f, 0.38f},
                                    {0, 128, 128, 4, false, 2.8f, 4.8f, 0.55f, 0.34f}, {1, 128, 64, 4, false, 5.0f, 1.9f, 0.34f, 0.23f},
                                    {3, 64, 64, 8, false, 2.5f, 2.2f, 0.25f, 0.30f},   {12, 128, 64, 3, true, 1.9f, 4.5f, 0.34f, 0.55f},
@@ -1143,7 +1159,7 @@ extern "C" int lbmk_igemm(const lbmk_igemm_desc* dp, void* stream) {
                                    {16, 192, 128, 2, true, 0.f, 12.0f, 0.58f, 0.90f},    // offered to batched launches only (below)
                                    // ping-pong tiles: about 8 % less time per K step than their 16-wave counterparts (in-kernel
                                    // stamps: 1.29 vs 1.41 us at 256x256), a slightly longer epilogue (8 waves store the tile)
-                                   {17, 256, 256, 1, true, 0.f, 12.8f, 1.01f, 1.10f},  {18, 256, 160, 1, true, 0.f, 9.0f, 1.02f, 0.99f},
+                                   {17, 256, 256, 1, true, 0.f, 12.8f, 1.01f, 1.10f},  {18, 256, 160, 1, true, 0.f, 7.5f, 1.02f, 0.99f},
                                    // shared activation rows, one persistent workgroup per CU (3x3 stride-1 convolutions up to 256 columns)
                                    {15, 384, 128, 1, true, 0.f, 8.1f, 1.48f, 1.48f}};
       const int cus = lbmk_num_cus();
