@@ -28,7 +28,10 @@ bool gn_plan(int B, int HW, int C, int G, GnPlan* pl) {
   pl->S = S;
   pl->nch = C / 8 / S;
   pl->rpp = 256 / pl->nch;
-  int want = (2048 + B * S - 1) / (B * S);
+  // slabs per image do NOT depend on the batch size: the order of the partial sums (hence the last bit of mean / rstd,
+  // hence every output) must be the same for an image alone and inside a batch
+  (void)B;
+  int want = (2048 + S - 1) / S;
   int max_slabs = (HW + pl->rpp * 8 - 1) / (pl->rpp * 8);
   if (max_slabs < 1) max_slabs = 1;
   int nslab = want < max_slabs ? want : max_slabs;
