@@ -273,9 +273,16 @@ def main():
         # step is bracketed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch of the
         # reference operation (an upsampling convolution counts its 9 taps although the four parity convolutions
         # that compute it multiply 4/9 of them: "executed" is the rate of the products actually multiplied)
-        ops.igemm_profile_begin()
-        one_step(model, images, enc_eps, args.nfe)
-        prof = ops.igemm_profile_end()
+        # This pass runs on ONE stream so that a launch's duration is its own: the timed steps above run the two halves
+        # of the batch on two streams (lbm_amd.streams), where concurrent kernels stretch each other's durations.
+        from lbm_amd import streams
+        split, streams._SPLIT = streams._SPLIT, False
+        try:
+            ops.igemm_profile_begin()
+            one_step(model, images, enc_eps, args.nfe)
+            prof = ops.igemm_profile_end()
+        finally:
+            streams._SPLIT = split
         tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -285,7 +292,9 @@ def main():
                                        "this command; not measured in this run)") if pmc_traffic(args)[1] else None,
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
-                    "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3)}
+                    "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3),
+                    "measured_on": "one stream, one extra untimed step" + (
+                        " (the timed steps overlap two half-batches on two streams)" if split else "")}
         # the other kernels of the step, same event-bracketed measurement: the attention kernel against the MFMA
         # peak, the normalisation / softmax passes against HBM (algorithmic bytes: 2 B read + 2 B written per element,
         # plus 2 B for a separate statistics read; softmax 4 B read + 2 B written)

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, streams
 from ..base.base_model import BaseModel
 from ..schedulers import FlowMatchEulerDiscreteScheduler
 from .lbm_config import LBMConfig
@@ -247,7 +247,7 @@ class LBMModel(BaseModel):
             # the timestep vector is filled on the device from the host scalar: no host-to-device copy in the
             # loop, so the whole call can be captured into a HIP graph
             t_vec = torch.full((denoiser_input.shape[0],), float(t), dtype=sched.timesteps.dtype, device=z.device)
-            pred = self.denoiser(sample=denoiser_input, timestep=t_vec, conditioning=conditioning)
+            pred = self._denoise_batch(denoiser_input, t_vec, conditioning)
             last = i == n - 1
             eps = None
             if not last:
@@ -264,6 +264,23 @@ class LBMModel(BaseModel):
                                             bridge_sigma=self.bridge_noise_sigma)
             sample = sample.to(z.dtype)
         return self.vae.decode(sample) if self.vae is not None else sample
+
+    def _denoise_batch(self, x: torch.Tensor, t_vec: torch.Tensor, conditioning) -> torch.Tensor:
+        """One denoiser evaluation; batches of 16 or more run as two halves on two streams (lbm_amd.streams: measured -1.9 % on the 1024^2 batch-16 step, nothing at 8)."""
+        n = x.shape[0]
+        if not streams.enabled(x) or n < 16:
+            return self.denoiser(sample=x, timestep=t_vec, conditioning=conditioning)
+        h = (n + 1) // 2
+
+        def part(lo, hi):
+            cond = conditioning
+            if conditioning:
+                cond = {k: ({kk: vv[lo:hi] for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in conditioning.items()}
+            return (x[lo:hi], t_vec[lo:hi], cond)
+
+        outs = streams.run_slices(lambda p: self.denoiser(sample=p[0], timestep=p[1], conditioning=p[2]),
+                                  (part(0, h), part(h, n)), device=x.device)
+        return torch.cat(outs, dim=0)
 
     def log_samples(self, batch: Dict[str, Any], input_shape: Optional[Tuple[int, int, int]] = None,
                     max_samples: Optional[int] = None, num_steps: Union[int, List[int]] = 20):

@@ -13,10 +13,10 @@ from typing import List, Optional
 
 import torch
 
-from ... import ops
+from ... import ops, streams
 from ..base.base_model import BaseModel
 from ..utils import Tiler, gaussian_weights_1d, tile_starts
-from .autoencoder_kl import AutoencoderKL
+from .autoencoder_kl import AutoencoderKL, DiagonalGaussianDistribution
 from .autoencoderKL_config import AutoencoderKLDiffusersConfig
 
 
@@ -46,9 +46,15 @@ class AutoencoderKLDiffusers(BaseModel):
         """(posterior sample - shift) * scaling_factor, in chunks of ``batch_size`` images
         (autoencoderKL.py:60-69).  ``eps``: optional NCHW noise for the posterior sample."""
         latents: List[torch.Tensor] = []
-        for i in range(0, x.shape[0], batch_size):
-            dist = self.vae_model.encode(x[i:i + batch_size]).latent_dist
-            e = None if eps is None else eps[i:i + batch_size]
+        chunks = [x[i:i + batch_size] for i in range(0, x.shape[0], batch_size)]
+        if len(chunks) > 1 and streams.enabled(x):
+            # the chunks are independent: alternate them between two streams (the posterior draws stay in chunk order)
+            moments = streams.run_slices(lambda c: self.vae_model.encode(c).latent_dist.moments, chunks)
+            dists = [DiagonalGaussianDistribution(m, self.vae_model.config.latent_channels, x.dtype) for m in moments]
+        else:
+            dists = [self.vae_model.encode(c).latent_dist for c in chunks]
+        for k, dist in enumerate(dists):
+            e = None if eps is None else eps[k * batch_size:(k + 1) * batch_size]
             latents.append(dist.sample(generator=generator, eps=e, shift=float(self.shift_factor),
                                        scale=float(self.vae_model.config.scaling_factor)))
         return latents[0] if len(latents) == 1 else torch.cat(latents, dim=0)
@@ -72,7 +78,7 @@ class AutoencoderKLDiffusers(BaseModel):
         zs = ops.scale_shift(zc, 1.0 / float(self.vae_model.config.scaling_factor), float(self.shift_factor))
         use_tiling = z.shape[2] > self.tiling_size[0] or z.shape[3] > self.tiling_size[1]
         if not use_tiling:
-            img = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(zs, dtype=adt))
+            img = streams.run_halves(self.vae_model.decode_nhwc, ops.nchw_to_nhwc(zs, dtype=adt))
             return ops.nhwc_to_nchw(img, self.vae_model.config.out_channels, out_dtype=z.dtype)
         return self._tiled_decode(zs)
 
@@ -97,7 +103,7 @@ class AutoencoderKLDiffusers(BaseModel):
                 t = zs[:, :, y0:y0 + th, x0:x0 + tw]
                 t = torch.nn.functional.pad(t, (0, tw - t.shape[3], 0, th - t.shape[2]))   # zero pad to the tile size
                 tiles.append(t)
-            dec = self.vae_model.decode_nhwc(ops.nchw_to_nhwc(torch.cat(tiles, 0), dtype=self.vae_model.compute_dtype))   # [len*B, th*f, tw*f, 8]
+            dec = streams.run_halves(self.vae_model.decode_nhwc, ops.nchw_to_nhwc(torch.cat(tiles, 0), dtype=self.vae_model.compute_dtype))   # [len*B, th*f, tw*f, 8]
             for k, (y0, x0) in enumerate(group):
                 hh, ww = min(th, H - y0) * f, min(tw, W - x0) * f
                 wy = torch.tensor(gaussian_weights_1d(hh, hh / 2), dtype=torch.float32, device=zs.device)

@@ -187,6 +187,40 @@ def _lbm(small_unet, vae_w, sigma=0.005):
     return model
 
 
+def test_two_stream_batch_split_is_transparent(small_unet, vae, cuda):
+    """Batches of 16 run the VAE chunks and the denoiser halves on two HIP streams (lbm_amd.streams): the same bits
+    as on one stream, twice in a row (the second pass reuses the side pools' memory), and the same bits an image
+    gives in a batch of 3 (no split)."""
+    from lbm_amd import streams
+    m, _ = small_unet
+    w, _ = vae
+    model = _lbm(m, w)
+    g = torch.Generator().manual_seed(31)
+    x = (torch.rand(16, 3, 128, 128, generator=g) * 2 - 1).to(BF).to(cuda)
+    enc_eps = torch.randn(16, 4, 16, 16, generator=g).to(BF).to(cuda)
+    eps_list = [torch.randn(16, 4, 16, 16, generator=g).to(BF).to(cuda) for _ in range(2)]
+
+    def run(xs, es, el):
+        with torch.no_grad():
+            z = w.encode(xs, eps=es)
+            return model.sample(z, num_steps=3, eps_list=el)
+
+    with torch.no_grad():
+        assert streams._SPLIT and streams.enabled(x)
+    a = run(x, enc_eps, eps_list)
+    b = run(x, enc_eps, eps_list)
+    old, streams._SPLIT = streams._SPLIT, False
+    try:
+        c = run(x, enc_eps, eps_list)
+    finally:
+        streams._SPLIT = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    small = run(x[5:8].contiguous(), enc_eps[5:8].contiguous(), [e[5:8].contiguous() for e in eps_list])
+    assert torch.equal(small, a[5:8])
+
+
 @pytest.mark.parametrize("steps", [1, 4])
 def test_pipeline_encode_sample_decode(small_unet, vae, cuda, steps):
     """vae.encode -> LBMModel.sample(n steps) -> vae.decode (the evaluate() path, inference.py:57-64)."""
