@@ -3,6 +3,7 @@
 SDXL-style UNet evaluation + Euler step -> VAE decode), bf16, batch 16 per GPU.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus 8 --steps 5 --warmup 2        (starts its own 8 ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -61,7 +62,8 @@ def one_step(model, images, enc_eps, nfe):
 
 def cpu_baseline(model, threads):
     """The fp32 CPU oracle (a restatement of the reference's diffusers-based path, kind 'port') on a
-    bounded sample: one 512x512 image, 1 NFE (the reference's CPU-runnable configuration)."""
+    bounded sample: 512x512 images, 1 NFE (the reference's CPU-runnable configuration); one untimed warm-up
+    pass, then the median of three timed passes."""
     from oracle import bridge_ref as br
     from oracle import diffusers_ref as dr
     torch.set_num_threads(threads)
@@ -69,21 +71,49 @@ def cpu_baseline(model, threads):
     vsd = {k: v.detach().float().cpu() for k, v in model.vae.vae_model.state_dict().items()}
     from lbm_amd.inference.utils import sdxl_style_unet_kwargs
     cfg = sdxl_style_unet_kwargs()
-    n = 4
+    n = 2
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(n, 3, 512, 512, generator=g) * 2 - 1
     eps = torch.randn(n, 4, 64, 64, generator=torch.Generator().manual_seed(4321))
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        z = dr.posterior_sample(dr.vae_encode_moments(vsd, x), eps) * 0.13025
-        lat = br.sample(z, lambda s, t: dr.unet_forward(usd, cfg, s, t), 1, [], 0.005)
-        img = dr.vae_decode(vsd, lat / 0.13025)
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(img).all()
+
+    def one_pass():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            z = dr.posterior_sample(dr.vae_encode_moments(vsd, x), eps) * 0.13025
+            lat = br.sample(z, lambda s, t: dr.unet_forward(usd, cfg, s, t), 1, [], 0.005)
+            img = dr.vae_decode(vsd, lat / 0.13025)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(img).all()
+        return dt
+
+    one_pass()
+    times = sorted(one_pass() for _ in range(3))
+    dt = times[1]
     return {"value": round(n / dt, 4), "unit": "images/s (512x512)", "cores": threads, "kind": "port",
-            "sample": f"{n} images 512x512, 1 NFE, fp32 torch CPU oracle, {dt:.1f} s "
+            "sample": f"{n} images 512x512 per pass, 1 NFE, fp32 torch CPU oracle; 1 warm-up pass, median of 3 timed "
+                      f"passes ({times[0]:.1f} / {times[1]:.1f} / {times[2]:.1f} s) "
                       f"(5.33 TFLOP/image; the 1024x1024 workload is 23.25 TFLOP/image, i.e. "
                       f"~{n / dt * 5.33 / 23.25:.3f} images/s extrapolated by FLOPs)"}
+
+
+def measured_gemm_ceiling(device, reps=5):
+    """What the matrix pipe delivers on this box under a large dense product of random bf16 data (16384 x 16384 x 8192,
+    one igemm launch per rep, HIP events on the launch stream): the DVFS-limited ceiling next to the nominal peak."""
+    from lbm_amd import ops
+    g = torch.Generator(device=device).manual_seed(5)
+    a = torch.randn(16384, 8192, generator=g, device=device, dtype=torch.float32).to(BF)
+    b = torch.randn(16384, 8192, generator=g, device=device, dtype=torch.float32).to(BF)
+    out = torch.empty(16384, 16384, dtype=BF, device=device)
+    ops.gemm_nt(a, b, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.gemm_nt(a, b, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"value": round(2.0 * 16384 * 16384 * 8192 / (ms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+            "shape": "16384 x 16384 x 8192 bf16 NT product, random N(0,1) operands, lbmk_igemm", "ms": round(ms, 3), "reps": reps}
 
 
 PMC_TRAFFIC_FILES = ("profiles/r02_pmc_igemm_step_traffic_v2.json", "profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
@@ -184,6 +214,63 @@ def extra_training(model, device, rank, world, dist, res, batch, steps):
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
 
 
+def launch_ranks(n, argv, timeout_s=None):
+    """Starts ``n`` ranks of this script (one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in each child's
+    environment, rendezvous on 127.0.0.1 at a free port), as the reference's entry point starts its own ranks
+    (examples/training/train_base.py:114-132: devices=torch.cuda.device_count()).  The children inherit stdout, so
+    rank 0's JSON line is this command's output.  Returns 0 when every rank did, else the first non-zero status;
+    when one rank fails the others are terminated (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    status, t0 = 0, time.time()
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is None:
+                continue
+            live.remove(pr)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {procs.index(pr)} exited with status {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                for other in live:
+                    other.terminate()
+        if live and timeout_s is not None and time.time() - t0 > timeout_s:
+            status = status or 124
+            for other in live:
+                other.kill()
+        time.sleep(0.05)
+    return status
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the rank plumbing of the benchmark without a GPU (gloo): rendezvous, barrier, max over ranks, and
+    rank 0's one JSON line.  LBM_BENCH_DRY_FAIL_RANK=r makes rank r exit with status 7 before the rendezvous (the
+    launcher must then stop the others and report failure)."""
+    from lbm_amd import dist as D
+    if os.environ.get("LBM_BENCH_DRY_FAIL_RANK") == str(rank):
+        return 7
+    dist = D.init("gloo")
+    t0 = time.perf_counter()
+    D.barrier(dist)
+    el = D.max_over_ranks(time.perf_counter() - t0 + rank, dist)      # "+ rank": the max must come from the last rank
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks_s": round(el, 3)}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,12 +285,22 @@ def main():
     ap.add_argument("--extras-budget-s", type=float, default=420.0,
                     help="wall-clock limit for everything after the headline region; on expiry the line is printed without "
                          "what is missing and the process exits")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only, on the CPU over gloo: rendezvous, barrier, max over ranks, one JSON line "
+                         "(what the launcher test runs where there is no GPU)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (and never will); it starts the N
+        # ranks as child processes, relays what they print and exits with the first failing status
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from lbm_amd import dist as D
     rank, local_rank, world = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = D.init("nccl", device)       # nccl = RCCL; used for the timing barrier / max only
@@ -233,12 +330,17 @@ def main():
     assert out.shape == (args.batch, 3, args.res, args.res) and bool(torch.isfinite(out.float()).all())
     elapsed = D.max_over_ranks(elapsed, dist, device)
 
-    state = {"roofline": None, "secondary": None, "cpu": None, "extra": {}, "done": False}
+    import threading
+    state = {"roofline": None, "secondary": None, "cpu": None, "extra": {}, "done": False, "in_flight": "roofline pass"}
+    emit_lock = threading.Lock()
 
     def emit():
-        if rank != 0 or state["done"]:
+        with emit_lock:
+            if state["done"]:
+                return
+            state["done"] = True
+        if rank != 0:
             return
-        state["done"] = True
         total_images = args.batch * world * args.steps
         line = {
             "metric": f"images/sec ({args.res}^2, {args.nfe}-NFE LBM) whole node", "value": round(total_images / elapsed, 3),
@@ -255,13 +357,14 @@ def main():
         print(json.dumps(line), flush=True)
 
     # everything below is measured AFTER the headline region; a watchdog bounds it so that a stall there (first
-    # multi-rank collective of the training record, a slow host) can never cost the headline line
-    import threading
-
+    # multi-rank collective of the training record, a slow host) can never cost the headline line;
+    # costs the process its clean exit status but not the headline line: exit status 3 on every rank
     def expire():
-        state["extra"]["aborted"] = f"post-headline measurements exceeded {args.extras_budget_s:.0f} s"
+        state["extra"]["aborted"] = (f"post-headline measurements exceeded {args.extras_budget_s:.0f} s while running: "
+                                     f"{state['in_flight']}")
         emit()
-        os._exit(0)
+        sys.stdout.flush()
+        os._exit(3)
 
     watchdog = threading.Timer(args.extras_budget_s, expire)
     watchdog.daemon = True
@@ -281,8 +384,16 @@ def main():
             ops.igemm_profile_begin()
             one_step(model, images, enc_eps, args.nfe)
             prof = ops.igemm_profile_end()
+            # the same one-stream step without the per-launch events: what the kernels' shares are shares OF
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            one_step(model, images, enc_eps, args.nfe)
+            e1.record()
+            torch.cuda.synchronize()
+            one_stream_ms = e0.elapsed_time(e1)
         finally:
             streams._SPLIT = split
+        ceiling = measured_gemm_ceiling(device)
         tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -292,14 +403,17 @@ def main():
                                        "this command; not measured in this run)") if pmc_traffic(args)[1] else None,
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
-                    "share_of_step_time": round(prof["ms"] / (elapsed / args.steps * 1e3), 3),
+                    "measured_ceiling": ceiling,
+                    "frac_of_measured_ceiling": round(tf / ceiling["value"], 4),
+                    "one_stream_step_ms": round(one_stream_ms, 2),
+                    "share_of_step_time": round(prof["ms"] / one_stream_ms, 3),
                     "measured_on": "one stream, one extra untimed step" + (
                         " (the timed steps overlap two half-batches on two streams)" if split else "")}
         # the other kernels of the step, same event-bracketed measurement: the attention kernel against the MFMA
         # peak, the normalisation / softmax passes against HBM (algorithmic bytes: 2 B read + 2 B written per element,
         # plus 2 B for a separate statistics read; softmax 4 B read + 2 B written)
         secondary = []
-        step_ms = elapsed / args.steps * 1e3
+        step_ms = one_stream_ms
         for kind, (ms, work, n) in sorted(prof["aux"].items()):
             if kind == "flash_attn":
                 ach, peak, unit, bound = work / (ms * 1e-3) / 1e12, MFMA_BF16_DENSE_PEAK_TFLOPS, "TFLOP/s", "mfma"
@@ -316,6 +430,7 @@ def main():
                          ("nfe4_1024_b8", lambda: extra_inference(model, device, rank, world, dist, 1024, 8, 4, 2)),
                          ("res2048_b8", lambda: extra_inference(model, device, rank, world, dist, 2048, 8, 1, 1)),
                          ("train_512_b8", lambda: extra_training(model, device, rank, world, dist, 512, 8, 3))):
+            state["in_flight"] = name
             try:
                 state["extra"][name] = fn()
             except Exception as err:          # an extra must never cost the headline line
@@ -323,6 +438,7 @@ def main():
                 break
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the box's CPU share for a one-GPU job is 16 cores (os.cpu_count() reports the whole machine)
+        state["in_flight"] = "cpu_baseline"
         state["cpu"] = cpu_baseline(model, min(16, os.cpu_count() or 1))
     watchdog.cancel()
     emit()

@@ -28,12 +28,29 @@ class _Cached:
     """Small per-module cache keyed on the identity/version of the source parameters."""
 
     def _cached(self, name, params, build):
+        """The cached value, built on a miss.  A build enqueues kernels on the CURRENT stream while the entry
+        becomes visible to the host at once, so another stream (the two batch halves of lbm_amd.streams run the
+        same layers on two streams) could launch a consumer before the pack is written.  An entry built on the GPU
+        therefore carries an event recorded behind its build: a hit from any other stream waits on it, until the
+        event has completed (after that the pack is plain resident memory for every stream)."""
         key = _stamp(*params)
         ent = self.__dict__.get("_pack_" + name)
         if ent is None or ent[0] != key:
             with torch.no_grad():
-                ent = (key, build())
+                val = build()
+            ent = [key, val, None, 0, None]              # key, value, build event, build stream, device
+            p0 = next((p for p in params if p is not None), None)
+            if p0 is not None and p0.is_cuda and not torch.cuda.is_current_stream_capturing():
+                s = torch.cuda.current_stream(p0.device)
+                ent[2], ent[3], ent[4] = s.record_event(), s.cuda_stream, p0.device
             self.__dict__["_pack_" + name] = ent
+        elif ent[2] is not None and not torch.cuda.is_current_stream_capturing():
+            if ent[2].query():
+                ent[2] = None
+            else:
+                s = torch.cuda.current_stream(ent[4])
+                if s.cuda_stream != ent[3]:
+                    s.wait_event(ent[2])
         return ent[1]
 
 

@@ -549,7 +549,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, out_dtype=bf16, alpha: float = 
         if mode == 2:
             assert rowmax.dtype == torch.float32 and rowmax.is_contiguous() and rowmax.numel() == max(d.batch, 1) * M
             d.smx_max = rowmax.data_ptr()
-    _igemm(d)
+    if smx is not None and smx[0] == 1:
+        # pass 1 of the two-pass softmax repeats the scores product of pass 2: multiplied, but not an operation of the
+        # reference (softmax(q k^T) v is 4 N^2 C FLOP), so it counts as executed work only
+        _igemm(d, 0.0, 2.0 * d.M * d.N * d.K * max(d.batch, 1))
+    else:
+        _igemm(d)
     return out
 
 

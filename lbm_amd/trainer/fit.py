@@ -56,7 +56,10 @@ def fit(pipeline, train_loader: Iterable, max_epochs: int, save_dir=None, save_i
     rank = pipeline.dist.get_rank() if pipeline.dist is not None else 0
     device = getattr(pipeline.model, "device", None)
     save_dir = None if save_dir is None else Path(save_dir)
-    for epoch in range(max_epochs):
+    # a resumed run continues in the epoch the checkpoint was written in (the epoch counter only names checkpoints
+    # and bounds the loop; like Lightning's mid-epoch resume without a stateful loader, the loader starts over)
+    for epoch in range(getattr(pipeline, "epoch", 0), max_epochs):
+        pipeline.epoch = epoch
         for batch in train_loader:
             if to_device is not None:
                 batch = to_device(batch)
@@ -70,4 +73,5 @@ def fit(pipeline, train_loader: Iterable, max_epochs: int, save_dir=None, save_i
                 pipeline.save_checkpoint(str(save_dir / checkpoint_name(epoch, step)), write=rank == 0)
             if max_steps is not None and step >= max_steps:
                 return step
+    pipeline.epoch = max_epochs
     return pipeline.global_step

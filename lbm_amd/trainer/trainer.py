@@ -202,6 +202,15 @@ class GradReducer:
                     p._lbmk_grad_sink = sink
                 p.register_post_accumulate_grad_hook(self._make_hook(g, pi))
         self._gindex = {id(g): gi for gi, g in enumerate(groups)}
+        # ONE order in which buckets go on the wire, the same on every rank whatever order the gradients arrive in
+        # (a collective pairs up by issue order: two ranks sending different buckets at the same position would hang
+        # or, with equal sizes, sum one bucket with another).  Buckets fill from the front of each flat buffer
+        # (reverse registration order), so that is the order; a bucket whose turn has not come waits, sent or flushed
+        # by finish() behind its predecessors.
+        self._order = [(gi, b) for gi, g in enumerate(groups) for b in range(len(g.buckets))]
+        self._order_pos = {gb: k for k, gb in enumerate(self._order)}
+        self._complete = set()
+        self._cursor = 0
 
     def on_side_stream(self, fn, reads=()):
         """Runs ``fn`` (kernel launches) on the side stream, ordered after everything enqueued so far on the current
@@ -249,7 +258,18 @@ class GradReducer:
         left = self._pending[id(group)]
         left[bucket] -= 1
         if left[bucket] == 0:
-            self._send(group, bucket)
+            self._complete.add((self._gindex[id(group)], bucket))
+            self._send_in_order(flush=False)
+
+    def _send_in_order(self, flush: bool):
+        """sends the buckets whose turn has come: the next of the fixed order while it is complete (all of the rest
+        when flushing at the end of the step)"""
+        while self._cursor < len(self._order):
+            gi, b = self._order[self._cursor]
+            if not flush and (gi, b) not in self._complete:
+                return
+            self._send(self.groups[gi], b)
+            self._cursor += 1
 
     def _make_hook(self, group, index):
         def hook(_param):
@@ -261,6 +281,7 @@ class GradReducer:
         self.written = set()
         self.touched = [set() for _ in self.groups]
         self._pending = {id(g): [c for (_, _, c) in g.buckets] for g in self.groups}
+        self._complete, self._cursor = set(), 0
         for g in self.groups:
             g.grad.zero_()
             g.rebind_grads()
@@ -274,13 +295,9 @@ class GradReducer:
         self._join_streams()
         mean_loss = None if loss is None else loss.detach().float()
         if self.dist is not None:
-            # parameters that received no gradient this step never fired their hook: exchange what is left
-            for g in self.groups:
-                left = self._pending[id(g)]
-                for b, c in enumerate(left):
-                    if c > 0:
-                        self._send(g, b)
-                        left[b] = 0
+            # parameters that received no gradient this step never fired their hook: their buckets, and every bucket
+            # waiting behind them, go out now, in the fixed order
+            self._send_in_order(flush=True)
             # one small vector: a flag per parameter (received a gradient on this rank) + the local loss
             # (the reference logs the loss with sync_dist=True, src/lbm/trainer/trainer.py:220-227)
             dev = self.groups[0].flat.device
@@ -351,6 +368,7 @@ class HipAdamW:
             n = g.numel // g.shards if sharded else g.numel
             g.m = torch.zeros(n, dtype=torch.float32, device=g.flat.device)
             g.v = torch.zeros(n, dtype=torch.float32, device=g.flat.device)
+            g.steps = [0] * len(g.params)          # updates each parameter has taken (bias correction)
 
     def _moment_range(self, g, s, e):
         if not self.sharded:
@@ -363,14 +381,29 @@ class HipAdamW:
                 return o, o + (e - s)
         raise AssertionError("update range outside this rank's slices")
 
-    def step(self, grad_scale: float = 1.0, ranges=None):
+    def step(self, grad_scale: float = 1.0, ranges=None, touched=None):
+        """``ranges``: per group, the flat ranges to update (this rank's slices of the touched parameters); ``touched``:
+        per group, the indices of the parameters that received a gradient on some rank.  The bias correction uses a
+        step count PER PARAMETER, like torch.optim.AdamW's per-parameter state: a parameter that received no gradient
+        in a step does not age, so one that joins late starts at step 1.  While every parameter has been touched in
+        every step (the usual case) that is one count and one launch per contiguous range."""
         self.step_count += 1
         for gi, (g, pg) in enumerate(zip(self.groups, self.param_groups)):
             todo = [(0, g.numel)] if ranges is None else ranges[gi]
-            for s, e in todo:
-                ms, me = self._moment_range(g, s, e)
-                ops.adamw_step(g.flat[s:e], g.grad[s:e], g.m[ms:me], g.v[ms:me], lr=pg["lr"], betas=self.betas,
-                               eps=self.eps, weight_decay=self.weight_decay, step=self.step_count, grad_scale=grad_scale)
+            idx = range(len(g.params)) if touched is None else touched[gi]
+            for i in idx:
+                g.steps[i] += 1
+            counts = {g.steps[i] for i in idx}
+            if len(counts) <= 1:
+                plan = [(next(iter(counts)) if counts else self.step_count, todo)]
+            else:
+                plan = [(c, intersect_ranges(merge_ranges([(g.offsets[i], g.offsets[i] + (g.params[i].numel() + 7) // 8 * 8)
+                                                           for i in idx if g.steps[i] == c]), todo)) for c in sorted(counts)]
+            for count, rs in plan:
+                for s, e in rs:
+                    ms, me = self._moment_range(g, s, e)
+                    ops.adamw_step(g.flat[s:e], g.grad[s:e], g.m[ms:me], g.v[ms:me], lr=pg["lr"], betas=self.betas,
+                                   eps=self.eps, weight_decay=self.weight_decay, step=count, grad_scale=grad_scale)
 
     def invalidate(self):
         """the kernel (and the all-gather) wrote parameters through raw pointers: invalidate cached weight packs, and
@@ -393,13 +426,16 @@ class HipAdamW:
             g.grad.zero_()
 
     def state_dict(self):
-        return {"step": self.step_count, "m": [g.m for g in self.groups], "v": [g.v for g in self.groups]}
+        return {"step": self.step_count, "m": [g.m for g in self.groups], "v": [g.v for g in self.groups],
+                "param_steps": [list(g.steps) for g in self.groups]}
 
     def load_state_dict(self, sd):
         self.step_count = sd["step"]
-        for g, m, v in zip(self.groups, sd["m"], sd["v"]):
+        steps = sd.get("param_steps") or [[sd["step"]] * len(g.params) for g in self.groups]
+        for g, m, v, st in zip(self.groups, sd["m"], sd["v"], steps):
             g.m.copy_(m)
             g.v.copy_(v)
+            g.steps = [int(x) for x in st]
 
 
 class TrainingPipeline(nn.Module):
@@ -423,6 +459,7 @@ class TrainingPipeline(nn.Module):
         self.optims: List[Any] = []
         self.reducer: Optional[GradReducer] = None
         self.global_step = 0
+        self.epoch = 0               # epoch the next step belongs to (fit() keeps it; saved in checkpoints)
         self.timer = time.perf_counter()
 
     # ---- same selection rules as the reference (trainer.py:86-124) --------------------------------
@@ -496,7 +533,7 @@ class TrainingPipeline(nn.Module):
             raise
         if self.reducer is not None:
             scale, ranges, loss_mean = self.reducer.finish(out["loss"])
-            opt.step(grad_scale=scale, ranges=ranges)
+            opt.step(grad_scale=scale, ranges=ranges, touched=self.reducer.touched)
             self.reducer.gather_params()
             opt.invalidate()
             self.last_loss_mean = loss_mean          # 0-dim tensor (on the host under data parallelism): no extra sync
@@ -523,14 +560,18 @@ class TrainingPipeline(nn.Module):
         Under data parallelism with sharded moments every rank must call this (the moments are gathered);
         ``write=False`` on the ranks that should not write the file."""
         ckpt = {"state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-                "global_step": self.global_step}
+                "global_step": self.global_step, "epoch": self.epoch}
         if self.optims:
             opt = self.optims[0]
             sd = opt.state_dict()
             if isinstance(opt, HipAdamW):
-                ckpt["optimizer_states"] = [{"step": sd["step"], "m": [self._full_moments(g, g.m).cpu() for g in opt.groups],
-                                             "v": [self._full_moments(g, g.v).cpu() for g in opt.groups],
-                                             "numel": [g.numel for g in opt.groups]}]
+                # moments as the unpadded concatenation of the group's parameters (in the group's order): no trace of
+                # the bucket padding, which depends on the rank count and the exchange mode
+                ckpt["optimizer_states"] = [{"step": sd["step"],
+                                             "m": [self._param_coords(g, self._full_moments(g, g.m)).cpu() for g in opt.groups],
+                                             "v": [self._param_coords(g, self._full_moments(g, g.v)).cpu() for g in opt.groups],
+                                             "param_numel": [[p.numel() for p in g.params] for g in opt.groups],
+                                             "param_steps": sd["param_steps"]}]
             else:
                 ckpt["optimizer_states"] = [sd]
         if write:
@@ -553,6 +594,21 @@ class TrainingPipeline(nn.Module):
             self.dist.all_gather_into_tensor(full[s:e], full[a:c].clone())
         return full
 
+    @staticmethod
+    def _param_coords(g: "FlatGroup", full: torch.Tensor) -> torch.Tensor:
+        """flat-buffer coordinates (8-element parameter alignment, bucket tail padding) -> the parameters back to back"""
+        return torch.cat([full[o:o + p.numel()] for p, o in zip(g.params, g.offsets)])
+
+    @staticmethod
+    def _flat_coords(g: "FlatGroup", packed: torch.Tensor) -> torch.Tensor:
+        """inverse of _param_coords for THIS run's layout (padding positions hold zeros, as after construction)"""
+        full = torch.zeros(g.numel, dtype=packed.dtype, device=packed.device)
+        at = 0
+        for p, o in zip(g.params, g.offsets):
+            full[o:o + p.numel()] = packed[at:at + p.numel()]
+            at += p.numel()
+        return full
+
     def _my_moments(self, g: "FlatGroup", full: torch.Tensor) -> torch.Tensor:
         if not self._sharded():
             return full
@@ -568,6 +624,17 @@ class TrainingPipeline(nn.Module):
         unexpected = [k for k in sd if k not in own]
         if strict and (missing or unexpected):
             raise RuntimeError(f"checkpoint mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        states = ckpt.get("optimizer_states")
+        if states:
+            # checked BEFORE any weight is overwritten: a refused checkpoint leaves the pipeline as it was
+            if not self.optims:
+                self.configure_optimizers()
+            if isinstance(self.optims[0], HipAdamW):
+                want = [[p.numel() for p in g.params] for g in self.optims[0].groups]
+                if states[0].get("param_numel") != want:
+                    raise RuntimeError("optimizer state of the checkpoint does not match this pipeline's trainable "
+                                       "parameter groups (trainable_params / model differ from the run that wrote it)")
+            own = self.model.state_dict()        # configure_optimizers re-homes parameters into the flat buffers
         with torch.no_grad():
             for k, t in own.items():
                 if k in sd:
@@ -575,16 +642,14 @@ class TrainingPipeline(nn.Module):
         for p in self.model.parameters():
             torch.autograd.graph.increment_version(p)
         self.global_step = int(ckpt.get("global_step", 0))
-        states = ckpt.get("optimizer_states")
+        self.epoch = int(ckpt.get("epoch", 0))
         if states:
-            if not self.optims:
-                self.configure_optimizers()
             opt = self.optims[0]
             if isinstance(opt, HipAdamW):
                 st = states[0]
-                assert st["numel"] == [g.numel for g in opt.groups], "optimizer groups differ from the checkpoint's"
-                opt.load_state_dict({"step": st["step"], "m": [self._my_moments(g, t) for g, t in zip(opt.groups, st["m"])],
-                                     "v": [self._my_moments(g, t) for g, t in zip(opt.groups, st["v"])]})
+                opt.load_state_dict({"step": st["step"], "param_steps": st.get("param_steps"),
+                                     "m": [self._my_moments(g, self._flat_coords(g, t)) for g, t in zip(opt.groups, st["m"])],
+                                     "v": [self._my_moments(g, self._flat_coords(g, t)) for g, t in zip(opt.groups, st["v"])]})
             else:
                 opt.load_state_dict(states[0])
 

@@ -221,6 +221,47 @@ def test_two_stream_batch_split_is_transparent(small_unet, vae, cuda):
     assert torch.equal(small, a[5:8])
 
 
+def test_two_stream_split_as_the_very_first_forward(cuda):
+    """A FRESH model whose first forward is the two-stream split: every layer's packed weights are built by the half
+    that gets there first, on its own stream, and the other half must not read a pack before it is written (the cache
+    entry carries an event for that, layers._Cached).  Bit-equal to the one-stream result of the same weights."""
+    from lbm_amd import streams
+    from lbm_amd.models.unets import DiffusersUNet2DCondWrapper
+    from lbm_amd.models.vae import AutoencoderKL, AutoencoderKLDiffusers, AutoencoderKLDiffusersConfig
+
+    def fresh():
+        torch.manual_seed(0)
+        m = DiffusersUNet2DCondWrapper(**SMALL_UNET).to(BF).to(cuda).eval()
+        torch.manual_seed(1)
+        core = AutoencoderKL(scaling_factor=0.13025).to(BF)
+        w = AutoencoderKLDiffusers(AutoencoderKLDiffusersConfig(version="unused", tiling_size=(128, 128)),
+                                   vae_model=core).to(cuda).eval()
+        return _lbm(m, w), w
+
+    g = torch.Generator().manual_seed(33)
+    x = (torch.rand(16, 3, 128, 128, generator=g) * 2 - 1).to(BF).to(cuda)
+    enc_eps = torch.randn(16, 4, 16, 16, generator=g).to(BF).to(cuda)
+
+    def run(model, w):
+        with torch.no_grad():
+            return model.sample(w.encode(x, eps=enc_eps), num_steps=1)
+
+    model_a, w_a = fresh()
+    model_b, w_b = fresh()
+    torch.cuda.synchronize()
+    assert streams._SPLIT
+    cold = run(model_a, w_a)                      # first forward of model_a: packs are built inside the split
+    old, streams._SPLIT = streams._SPLIT, False
+    try:
+        one_stream = run(model_b, w_b)            # same weights, everything on the caller's stream
+    finally:
+        streams._SPLIT = old
+    warm = run(model_a, w_a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(cold.float()).all()
+    assert torch.equal(cold, one_stream) and torch.equal(cold, warm)
+
+
 @pytest.mark.parametrize("steps", [1, 4])
 def test_pipeline_encode_sample_decode(small_unet, vae, cuda, steps):
     """vae.encode -> LBMModel.sample(n steps) -> vae.decode (the evaluate() path, inference.py:57-64)."""
@@ -460,6 +501,16 @@ def test_get_model_evaluate_end_to_end(cuda, tmp_path):
     print(f"get_model/evaluate 1024x1024 (bucket of a 512x512 input): encode rel-L2 {zerr:.4f}, image PSNR {psnr:.1f} dB")
     assert zerr < 1e-2
     assert psnr >= 40.0
+    # the SAMPLED latent at full size (after the UNet and the Euler step, before the decoder): the latent criterion
+    # itself, relative L2 <= 1e-2 against the fp32 oracle; sample() returns the latent when the model holds no VAE
+    vae_kept, model.vae = model.vae, None
+    with torch.no_grad():
+        lat1 = model.sample(seen["z"], num_steps=1)
+    model.vae = vae_kept
+    lerr1 = rel_l2(lat1, lat_ref)
+    print(f"1-step sampled latent 128x128 (2.43 B-parameter UNet): rel-L2 {lerr1:.4f} against the fp32 oracle")
+    assert lat1.shape == lat_ref.shape == (1, 4, 128, 128)
+    assert lerr1 <= 1e-2
     # BASELINE config 3 at full size: 4-step sampling at 1024x1024 (the noise drawn after steps 0..2 injected on both
     # sides); LBMModel.sample returns the decoded image
     eps4 = [torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(60 + i)).to(BF) for i in range(3)]
@@ -468,6 +519,13 @@ def test_get_model_evaluate_end_to_end(cuda, tmp_path):
         lat4_ref = br.sample(z_ref, lambda s_, t: dr.unet_forward(usd, cfg, s_, t), 4, [e.float() for e in eps4], 0.005)
         img4_ref = dr.vae_decode(vsd, lat4_ref / 0.13025).clamp(-1, 1)
     assert img4.shape == img4_ref.shape == (1, 3, 1024, 1024)
+    vae_kept, model.vae = model.vae, None
+    with torch.no_grad():
+        lat4 = model.sample(seen["z"], num_steps=4, eps_list=[e.to(cuda) for e in eps4])
+    model.vae = vae_kept
+    lerr4 = rel_l2(lat4, lat4_ref)
+    print(f"4-step sampled latent 128x128: rel-L2 {lerr4:.4f} against the fp32 oracle")
+    assert lerr4 <= 1e-2
     mse4 = float(((img4 - img4_ref) ** 2).mean()) / 4.0
     psnr4 = 10 * math.log10(1.0 / max(mse4, 1e-12))
     print(f"4-step sampling 1024x1024: image PSNR {psnr4:.1f} dB against the fp32 oracle")
