@@ -57,3 +57,12 @@ with torch.no_grad():
         with dr.compute_dtype(BF):
             p16 = dr.unet_forward(usd, cfg, zr, ts)
         print(f"torch-bf16 (CPU) unet, identical input: rel {rel(p16, pred_ref_r):.5f}")
+    # the same UNet on a unit-variance latent (the module-level tests' input)
+    xn = torch.randn(1, 4, L, L, generator=g).to(BF)
+    rn = dr.unet_forward(usd, cfg, xn.float(), ts)
+    hn = model.denoiser(sample=xn.to(cuda), timestep=ts.to(cuda), conditioning={"cond": {}})
+    print(f"unet on N(0,1) input: hip rel {rel(hn, rn):.5f}")
+    if os.environ.get("DIAG_T16"):
+        with dr.compute_dtype(BF):
+            n16 = dr.unet_forward(usd, cfg, xn, ts)
+        print(f"torch-bf16 (CPU) unet on N(0,1) input: rel {rel(n16, rn):.5f}")
