@@ -3,7 +3,7 @@ from .training_config import TrainingConfig
 from .utils import StateDictAdapter, StateDictRenamer
 
 __all__ = ["TrainingConfig", "StateDictAdapter", "StateDictRenamer", "TrainingPipeline", "fit", "resolve_task_dir",
-           "resolve_resume_checkpoint", "checkpoint_name"]
+           "resolve_resume_checkpoint", "checkpoint_name", "main", "main_from_config", "task_keys", "TASKS"]
 
 
 def __getattr__(name):
@@ -11,4 +11,7 @@ def __getattr__(name):
     if name == "TrainingPipeline":
         from .trainer import TrainingPipeline
         return TrainingPipeline
+    if name in ("main", "main_from_config", "task_keys", "TASKS"):
+        import importlib
+        return getattr(importlib.import_module(__name__ + ".entry"), name)
     raise AttributeError(name)

@@ -55,6 +55,22 @@ def intersect_ranges(a, b):
     return out
 
 
+def _plain(obj):
+    """nested dict / list / scalar copy of a hyper-parameter record (anything else by its repr), so that the
+    checkpoint stays loadable with ``torch.load(..., weights_only=True)``"""
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if isinstance(obj, dict):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    if hasattr(obj, "to_dict"):
+        return _plain(obj.to_dict())
+    if hasattr(obj, "__dict__") and not isinstance(obj, type):
+        return _plain({k: v for k, v in vars(obj).items() if not k.startswith("_")})
+    return repr(obj)
+
+
 class FlatGroup:
     """Parameters of one optimizer group re-homed into flat buffers (parameters become views).
 
@@ -561,6 +577,8 @@ class TrainingPipeline(nn.Module):
         ``write=False`` on the ranks that should not write the file."""
         ckpt = {"state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
                 "global_step": self.global_step, "epoch": self.epoch}
+        if getattr(self, "hparams", None):
+            ckpt["hyper_parameters"] = _plain(self.hparams)     # what Lightning's save_hyperparameters keeps in the file
         if self.optims:
             opt = self.optims[0]
             sd = opt.state_dict()

@@ -82,3 +82,40 @@ def test_pixel_loss_without_vae_matches_reference(cuda, kind):
     assert rel_l2(out["pixel_recon_loss"].reshape(1), GOLD[f"pix.{kind}.pixel_recon_loss"]) < 1e-5
     assert rel_l2(out["latent_recon_loss"].reshape(1), GOLD[f"pix.{kind}.latent_recon_loss"]) < 1e-5
     assert rel_l2(out["loss"].reshape(1), GOLD[f"pix.{kind}.loss"]) < 1e-5
+
+
+def test_training_entry_runs_the_shipped_fill_lighting_simple_config(cuda, tmp_path):
+    """lbm_amd.trainer.main with the key set of examples/training/config/fill_lighting_simple.yaml and the real builder
+    (SD1.5-style UNet, lighting tokens, latent l2 + pixel l2, denoiser and conditioner trained): two optimisation steps
+    on an injected loader, a checkpoint per step, resumable by get_model-style loading (model.-prefixed keys)."""
+    from lbm_amd.trainer import main
+    g = torch.Generator().manual_seed(3)
+    R = 256            # latent 32x32: the mid-block attention sees 4x4 = 16 tokens (the training attention wants a multiple of 8)
+    batch = {"source": (torch.rand(2, 3, R, R, generator=g) * 2 - 1).to(torch.bfloat16),
+             "target": (torch.rand(2, 3, R, R, generator=g) * 2 - 1).to(torch.bfloat16),
+             "depth": torch.rand(2, 1, R, R, generator=g).to(torch.bfloat16),
+             "lighting_params": torch.rand(2, 8, generator=g)}
+    config = dict(
+        wandb_project="lbm-fill-lighting-simple", backbone_signature="stable-diffusion-v1-5/stable-diffusion-v1-5",
+        unet_input_channels=5, vae_num_channels=4, timestep_sampling="custom_timesteps", selected_timesteps=[250, 500, 750, 1000],
+        prob=[0.25, 0.25, 0.25, 0.25], pixel_loss_type="l2", pixel_loss_weight=1.0, latent_loss_type="l2", latent_loss_weight=1.0,
+        bridge_noise_sigma=0.005, conditioning_images_keys=[], conditioning_masks_keys=["depth"],
+        lighting_embedder_config=dict(mapping_size=256, scale=10.0, hidden_dim=512, out_dim=768, seq_len=5,
+                                      param_groups=[[0, 1], [2], [3, 4, 5], [6], [7]]),
+        lighting_condition_weight=10.0, concat_condition_weight=1.0, source_key="source", target_key="target",
+        train_data_root="unused", validation_data_root="unused", image_size=R, num_workers=0, batch_size=2,
+        learning_rate=4e-5, optimizer="AdamW", num_steps=[1, 4], log_interval=500, resume_from_checkpoint=False, max_epochs=2,
+        save_interval=1, resume_ckpt_path=None, save_ckpt_path=str(tmp_path))
+    torch.manual_seed(0)
+    losses = []
+    pipe = main("fill_lighting_simple", train_loader=[batch], allow_random_init=True, device=cuda,
+                on_step=lambda s, out: losses.append(float(out["loss"])), **config)
+    assert pipe.global_step == 2 and len(losses) == 2 and all(np.isfinite(losses))
+    groups = pipe.optims[0].groups
+    assert len(groups) == 2 and abs(groups[1].lr / groups[0].lr - 10.0) < 1e-9         # conditioner.* at 10x (trainer.py:95)
+    assert sum(p.numel() for g_ in groups for p in g_.params) > 859_000_000
+    names = sorted(p.name for p in (tmp_path / "fill_lighting_simple").glob("*.ckpt"))
+    assert names == ["epoch=0-step=1.ckpt", "epoch=1-step=2.ckpt"]
+    ck = torch.load(str(tmp_path / "fill_lighting_simple" / names[-1]), map_location="cpu", weights_only=True)
+    assert "model.denoiser.conv_in.weight" in ck["state_dict"] and ck["state_dict"]["model.denoiser.conv_in.weight"].shape[1] == 5
+    assert ck["hyper_parameters"]["embedder_1"]["out_dim"] == 768 or ck["hyper_parameters"]["embedder_0"]["out_dim"] == 768
