@@ -26,6 +26,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // file built -fno-slp-vectorize), LDS read offsets hoisted out of the loop, and the rescale of the output
 // accumulator only when some row's running maximum actually moved.  116 registers; 3 and 4 waves per SIMD measure
 // the same.
+//
+// FAST (inference; no log-sum-exp wanted): two vector instructions per score fewer.  (1) Q is multiplied by
+// scale * log2(e) once, when its fragments are loaded (one more bf16 rounding of an operand that was rounded to bf16
+// when it was stored), so the scores leave the MFMA in the exp2 domain; (2) the running maximum is subtracted INSIDE
+// the MFMA: the first product of a score tile takes -m (16 registers, rewritten only when m changes) as its C operand,
+// so p = exp2(s') needs no fma.  m is allowed to lag: it is raised (output and row sum rescaled, the tile's scores
+// shifted) only when some row's tile maximum exceeds it by more than 2^10, so p <= 1024 and the rescale branch runs a
+// handful of times per row; the softmax is unchanged up to f32 rounding (every term and the row sum carry the same
+// 2^-m).  Why this and not an overlap of the softmax with the MFMAs: on this chip a vector instruction beside MFMAs is
+// not free -- scripts/micro/mfma_filler.hip measures 32 cycles per v_mfma_f32_32x32x16_bf16 with up to 3 v_fma_f32
+// (or 2 v_exp_f32) behind it, and +1.9 cycles per further v_fma_f32 (+6.1 per v_exp_f32), for 1, 2 or 3 waves per SIMD
+// alike -- so the loop's time is its MFMA time plus most of its vector time, and only fewer vector instructions help.
+template <bool FAST>
 __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
@@ -51,7 +64,13 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
     const int qr = min(q0 + r, Nq - 1);
     const bf16_t* qp = Q + (int64_t)qr * ldq + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+      if (FAST) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)((float)qf[ks][e] * scale_log2e);
+      }
+    }
   }
 
   f32x16 o[2];
@@ -60,6 +79,12 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  // FAST: -c_m in every element, the C operand of a score tile's first product (c_m = 0 until the first tile sets it)
+  f32x16 negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  float c_m = 0.f;
+  constexpr float LAG = 10.f;      // m may lag a row's true maximum by 2^LAG
 
   // staging coordinates: two rows per thread for each of the K and V^T images
   const int slot = t & 7, rsub = t >> 3;
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(sK + kt * 32 * 128 + koff[ks]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero : s[kt], 0, 0, 0);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? (FAST ? negm : zero) : s[kt], 0, 0, 0);
       }
     }
     if (kv0 + KB > Nk) {   // mask the keys past the end (wave-uniform branch)
@@ -124,6 +149,46 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
         }
     }
     // ---- online softmax (row = lane pair (l, l^32)) -----------------------------------
+    float ps0 = 0.f, ps1 = 0.f;
+    bf16x8 pf[2][2];
+    if (FAST) {
+      // s holds s' = scores (exp2 domain) - c_m.  Tile maximum as a tree of three-input maxima (v_max3_f32).
+      float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[1][0]);
+#pragma unroll
+      for (int e = 2; e < 16; e += 2) mx = fmaxf(fmaxf(mx, s[0][e]), s[0][e + 1]);
+#pragma unroll
+      for (int e = 1; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s[1][e]), s[1][e + 1]);
+      mx = fmaxf(mx, s[1][15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (__builtin_amdgcn_ballot_w64(mx + c_m - LAG > m_run) != 0) {   // some row outgrew m by more than 2^LAG (or first tile)
+        const float m_new = fmaxf(m_run, mx + c_m);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        const float d = m_new - c_m;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[kt][e] -= d;
+        m_run = c_m = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[e] = -m_new;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[kt][e]);
+          const float p1 = __builtin_amdgcn_exp2f(s[kt][e + 1]);
+          ps0 += p0;
+          ps1 += p1;
+          pf[kt][e >> 3][e & 7] = (__bf16)p0;
+          pf[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
+        }
+    } else {
     float mx = s[0][0];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -147,8 +212,6 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
       m_run = m_new;
     }
     const float nm = -m_run;
-    float ps0 = 0.f, ps1 = 0.f;
-    bf16x8 pf[2][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -160,6 +223,7 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
         pf[kt][e >> 3][e & 7] = (__bf16)p0;
         pf[kt][e >> 3][(e & 7) + 1] = (__bf16)p1;
       }
+    }
     l_run += ps0 + ps1;
     // A lane pair (l, l + 32) holds the keys of a 16-key step interleaved in fours (l: 0-3 and 8-11, l + 32: 4-7 and
     // 12-15).  Swapping the second packed half of l with the first of l + 32 gives each lane 8 CONSECUTIVE keys
@@ -491,9 +555,15 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
   dim3 grid((Nq + QB - 1) / QB, H, B);
   hipStream_t s = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
+  static const bool no_fast = getenv("LBMK_NO_FLASH_FAST") != nullptr;
 #define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2, lse
   switch (Dh) {
-    case 64: hipLaunchKernelGGL(flash_fwd_d64_kernel, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 64:
+      // the log-sum-exp rows feed the backward kernels, which recompute the scores from the unscaled q: keep that
+      // pass's arithmetic; LBMK_NO_FLASH_FAST=1 does the same for inference (same-box A/B runs)
+      if (lse || no_fast) hipLaunchKernelGGL(flash_fwd_d64_kernel<false>, grid, dim3(256), 0, s, FA_ARGS);
+      else hipLaunchKernelGGL(flash_fwd_d64_kernel<true>, grid, dim3(256), 0, s, FA_ARGS);
+      break;
     case 8: hipLaunchKernelGGL(flash_fwd_gen_kernel<8>, grid, dim3(256), 0, s, FA_ARGS); break;
     case 16: hipLaunchKernelGGL(flash_fwd_gen_kernel<16>, grid, dim3(256), 0, s, FA_ARGS); break;
     case 32: hipLaunchKernelGGL(flash_fwd_gen_kernel<32>, grid, dim3(256), 0, s, FA_ARGS); break;
