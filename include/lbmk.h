@@ -319,10 +319,23 @@ int64_t lbmk_groupnorm_bwd_scratch_floats(int B, int HW, int C, int G);
 int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
                        const float* beta, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
                        int G, int silu, void* stream);
+/* The same with (a) dgamma / dbeta written in the parameters' own dtype (param_f32: 1 f32, 0 bf16), e.g. straight into
+ * the parameters' slots of a flat gradient buffer, and (b) `add` (bf16, x's shape, may be NULL): the gradient that reached
+ * the SAME input tensor through its other consumer -- the residual link around the block, torch autograd's accumulation
+ * of two gradients of one tensor -- added to dx in this pass instead of by a separate elementwise kernel:
+ * dx = bf16(bf16(dx_norm) + add). */
+int lbmk_groupnorm_bwd_ex(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
+                          const float* beta, void* dgamma, void* dbeta, int param_f32, const void* add, float* scratch,
+                          int B, int HW, int C, int G, int silu, void* stream);
 /* LayerNorm backward; dgamma_dbeta f32 [2][C] (row 0 dgamma, row 1 dbeta), may be NULL; C <= 2048 */
 int64_t lbmk_layernorm_bwd_scratch_floats(int rows, int C);
 int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma_dbeta,
                        float* scratch, int rows, int C, float eps, void* stream);
+/* LayerNorm backward with separate dgamma / dbeta destinations in the parameters' dtype and the fused residual-gradient
+ * add: see lbmk_groupnorm_bwd_ex (torch autograd of nn.LayerNorm inside diffusers' BasicTransformerBlock, whose input also
+ * feeds the residual sum).  dgamma and dbeta are both NULL or both set. */
+int lbmk_layernorm_bwd_ex(const void* x, const void* dy, void* dx, const float* gamma, void* dgamma, void* dbeta,
+                          int param_f32, const void* add, float* scratch, int rows, int C, float eps, void* stream);
 /* dx = dy * silu'(x), bf16, n % 8 == 0 */
 int lbmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
 /* GEGLU (diffusers GEGLU: hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)): h bf16 [rows][2F] */

@@ -106,6 +106,8 @@ SIGNATURES = {
     "lbmk_groupnorm_bwd": (i32, [vp] * 9 + [i32] * 5 + [vp]),
     "lbmk_layernorm_bwd_scratch_floats": (i64, [i32, i32]),
     "lbmk_layernorm_bwd": (i32, [vp] * 6 + [i32, i32, f32, vp]),
+    "lbmk_layernorm_bwd_ex": (i32, [vp] * 6 + [i32, vp, vp, i32, i32, f32, vp]),
+    "lbmk_groupnorm_bwd_ex": (i32, [vp] * 8 + [i32, vp, vp] + [i32] * 5 + [vp]),
     "lbmk_silu_bwd": (i32, [vp, vp, vp, i64, vp]),
     "lbmk_geglu_fwd": (i32, [vp, vp, i64, i32, vp]),
     "lbmk_geglu_bwd": (i32, [vp, vp, vp, i64, i32, vp]),

@@ -36,6 +36,24 @@ def _grad_sink(param):
     return ent if ent is not None and ent.active else None
 
 
+# LBM_NO_GRAD_FUSION=1: bias / norm gradients go through autograd's accumulation and residual-link gradients are added by
+# autograd (same-box A/B runs)
+import os
+GRAD_FUSION = os.environ.get("LBM_NO_GRAD_FUSION") is None
+
+
+def _param_slots(*params):
+    """(sink, slot views) when the gradients of these (small) parameters can be written straight into the trainer's flat
+    gradient buffer by the kernel that produces them, else (None, None)"""
+    if not GRAD_FUSION or any(p is None for p in params):
+        return None, None
+    sink = _grad_sink(params[0])
+    if sink is None or any(_grad_sink(p) is not sink for p in params[1:]):
+        return None, None
+    views = sink.slots(list(params))
+    return (sink, views) if views is not None else (None, None)
+
+
 def _linear_maybe_splitk(x, pw, residual):
     """the few-row, deep-K linear layers of a training step as a split-K launch (ops.splitk_chunks); None = not eligible"""
     if x.dtype != bf16 or pw.geglu or pw.KH != 1 or pw.w.dtype != bf16 or pw.N % 8:
@@ -87,7 +105,12 @@ class LinearFn(torch.autograd.Function):
             else:
                 dw = ops.gemm_tn(dy2, xc, out_dtype=weight.dtype)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2, out_dtype=weight.dtype)[0]
+            sink, views = _param_slots(ctx.mod.bias) if dy2.shape[1] == N else (None, None)
+            if sink is not None:
+                ops.colsum(dy2, out=views[0])
+                sink.commit([ctx.mod.bias])
+            else:
+                db = ops.colsum(dy2, out_dtype=weight.dtype)[0]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         if ctx.has_rv and ctx.needs_input_grad[4]:
@@ -141,7 +164,12 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 dw = wgrad().reshape(N, Cin, KH, KW).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2, out_dtype=weight.dtype)[0, :N]
+            sink, views = _param_slots(ctx.mod.bias) if npad == N else (None, None)
+            if sink is not None:
+                ops.colsum(dy2, out=views[0])
+                sink.commit([ctx.mod.bias])
+            else:
+                db = ops.colsum(dy2, out_dtype=weight.dtype)[0, :N]
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy
         if ctx.has_rv and ctx.needs_input_grad[4]:
@@ -150,39 +178,64 @@ class Conv2dFn(torch.autograd.Function):
 
 
 class GroupNormFn(torch.autograd.Function):
-    """GroupNorm with optional fused SiLU; gamma / beta are the module's parameters (any float dtype)."""
+    """GroupNorm with optional fused SiLU; gamma / beta are the module's parameters (any float dtype).
+
+    ``passthrough``: the Function also returns its input (as a second output) for the tensor's OTHER consumer, the
+    residual link around the block (x -> norm -> ... -> + x).  Both gradients of x then arrive at this node, and the
+    backward kernel adds the residual's to dx in its own pass, where autograd would launch an elementwise addition.
+    ``mod``: the module that owns gamma / beta (their gradients go straight into the trainer's flat gradient buffer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, groups, eps, silu):
+    def forward(ctx, x, weight, bias, groups, eps, silu, mod=None, passthrough=False):
         g32, b32 = ops.f32_of(weight), ops.f32_of(bias)
         y, stats = ops.groupnorm_train(x, g32, b32, groups, eps, silu)
         ctx.save_for_backward(x, stats, g32, b32)
         ctx.cfg = (groups, silu, weight.dtype)
-        return y
+        ctx.mod, ctx.passthrough = mod, passthrough
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, stats, g32, b32 = ctx.saved_tensors
         groups, silu, wdt = ctx.cfg
-        dx, dg, db = ops.groupnorm_bwd(x, dy.contiguous(), stats, g32, b32, groups, silu)
-        return (dx, *_cast_pair(dg, db, wdt), None, None, None)
+        sink, views = (None, None)
+        if ctx.mod is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            sink, views = _param_slots(ctx.mod.weight, ctx.mod.bias)
+        add = dres.contiguous() if dres is not None else None
+        if sink is not None:
+            dx = ops.groupnorm_bwd(x, dy.contiguous(), stats, g32, b32, groups, silu, add=add, dg_out=views[0], db_out=views[1])[0]
+            sink.commit([ctx.mod.weight, ctx.mod.bias])
+            return (dx, None, None, None, None, None, None, None)
+        dx, dg, db = ops.groupnorm_bwd(x, dy.contiguous(), stats, g32, b32, groups, silu, add=add)
+        return (dx, *_cast_pair(dg, db, wdt), None, None, None, None, None)
 
 
 class LayerNormFn(torch.autograd.Function):
+    """``mod`` / ``passthrough``: see GroupNormFn (x -> LayerNorm -> attention / feed-forward -> + x)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, mod=None, passthrough=False):
         g32, b32 = ops.f32_of(weight), ops.f32_of(bias)
         y = ops.layernorm(x, g32, b32, eps)
         ctx.save_for_backward(x, g32)
         ctx.cfg = (eps, weight.dtype)
-        return y
+        ctx.mod, ctx.passthrough = mod, passthrough
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, g32 = ctx.saved_tensors
         eps, wdt = ctx.cfg
-        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), g32, eps)
-        return (dx, *_cast_pair(dg, db, wdt), None)
+        sink, views = (None, None)
+        if ctx.mod is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            sink, views = _param_slots(ctx.mod.weight, ctx.mod.bias)
+        add = dres.contiguous() if dres is not None else None
+        if sink is not None:
+            dx = ops.layernorm_bwd(x, dy.contiguous(), g32, eps, add=add, dg_out=views[0], db_out=views[1])[0]
+            sink.commit([ctx.mod.weight, ctx.mod.bias])
+            return (dx, None, None, None, None, None)
+        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), g32, eps, add=add)
+        return (dx, *_cast_pair(dg, db, wdt), None, None, None)
 
 
 class SiluFn(torch.autograd.Function):

@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 
 // out[i] = sum over segments of partial[s][i]; out dtype 0 bf16 / 1 f32.  32 columns per workgroup, 8 segment
 // lanes per column with independent loads in flight; the 8 lane sums are added in a fixed order.
+// out_b != null: elements from `split` on go to out_b[i - split] (two destinations of one reduction: dgamma | dbeta).
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, void* __restrict__ out,
-                                                           int64_t GN, int nseg, int out_dtype) {
+                                                           int64_t GN, int nseg, int out_dtype, void* __restrict__ out_b = nullptr,
+                                                           int64_t split = 0) {
   __shared__ float red[8][33];
   const int t = threadIdx.x, cl = t & 31, sl = t >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + cl;
@@ -186,8 +188,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) a += red[k][t];
-    if (out_dtype) ((float*)out)[i] = a;
-    else ((bf16_t*)out)[i] = f2bf(a);
+    void* dst = out;
+    int64_t j = i;
+    if (out_b && i >= split) { dst = out_b; j = i - split; }
+    if (out_dtype) ((float*)dst)[j] = a;
+    else ((bf16_t*)dst)[j] = f2bf(a);
   }
 }
 
@@ -449,14 +454,19 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
 
 // pass 2b: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1;  gsum[b][g] = {sum_c gamma*s1, sum_c gamma*s2} / n
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ bc, const float* __restrict__ gamma,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ gsum,
+                                       void* __restrict__ dgamma, void* __restrict__ dbeta, int param_f32, float* __restrict__ gsum,
                                        int B, int C, int G, float inv_n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < C) {
     float a = 0.f, bsum = 0.f;
     for (int b = 0; b < B; ++b) { bsum += bc[((int64_t)b * C + i) * 2]; a += bc[((int64_t)b * C + i) * 2 + 1]; }
-    if (dgamma) dgamma[i] = a;
-    if (dbeta) dbeta[i] = bsum;
+    if (param_f32) {
+      if (dgamma) ((float*)dgamma)[i] = a;
+      if (dbeta) ((float*)dbeta)[i] = bsum;
+    } else {
+      if (dgamma) ((bf16_t*)dgamma)[i] = f2bf(a);
+      if (dbeta) ((bf16_t*)dbeta)[i] = f2bf(bsum);
+    }
   }
   if (i < B * G) {
     const int b = i / G, g = i - b * G, cpg = C / G;
@@ -476,7 +486,8 @@ template <bool SILU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ dx, const float* __restrict__ stats,
                                                            const float* __restrict__ gsum, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int HW, int C, int G, int64_t total8) {
+                                                           const float* __restrict__ beta, int HW, int C, int G, int64_t total8,
+                                                           const bf16_t* __restrict__ add) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 8-channel chunk of one pixel
   if (gid >= total8) return;
   const int nch = C >> 3;
@@ -486,6 +497,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
   const int c0 = chunk * 8, cpg = C / G;
   const u16x8 xv = *(const u16x8*)(x + row * C + c0);
   const u16x8 dv = *(const u16x8*)(dy + row * C + c0);
+  u16x8 av;
+  if (add) av = *(const u16x8*)(add + row * C + c0);
   u16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -496,7 +509,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
     const float xh = (bf2f(xv.v[e]) - mu) * rs;
     float dz = bf2f(dv.v[e]);
     if (SILU) dz *= dsilu_f(xh * ga + be);
-    o.v[e] = f2bf(rs * (ga * dz - A - xh * Bq));
+    // the gradient of the tensor's other consumer (a residual link) is added to the ROUNDED gradient of this one, as
+    // a separate addition of two bf16 tensors would
+    const float v = bf2f(f2bf(rs * (ga * dz - A - xh * Bq)));
+    o.v[e] = add ? f2bf(v + bf2f(av.v[e])) : f2bf(v);
   }
   *(u16x8*)(dx + row * C + c0) = o;
 }
@@ -506,7 +522,7 @@ template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                      bf16_t* __restrict__ dx, const float* __restrict__ gamma,
                                                      float* __restrict__ partial, int rows, int C, float eps,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, const bf16_t* __restrict__ add) {
   extern __shared__ float sm[];     // [4 waves][2][C] partials of dgamma, dbeta, summed over the waves in order
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nchunks = C >> 3;
@@ -568,6 +584,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         u16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.v[e] = f2bf(rstd * (ga[i][e] * dv[i][e] - m1 - xv[i][e] * m2));
+        if (add) {   // + the gradient that reached the same tensor through its residual link (sum of two bf16 tensors)
+          const u16x8 a = *(const u16x8*)(add + (int64_t)row * C + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.v[e] = f2bf(bf2f(o.v[e]) + bf2f(a.v[e]));
+        }
         *(u16x8*)(dx + (int64_t)row * C + c * 8) = o;
       }
     }
@@ -695,7 +716,15 @@ extern "C" int64_t lbmk_groupnorm_bwd_scratch_floats(int B, int HW, int C, int G
 extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
                                   const float* beta, float* dgamma, float* dbeta, float* scratch, int B, int HW, int C,
                                   int G, int silu, void* stream) {
+  return lbmk_groupnorm_bwd_ex(x, dy, dx, stats, gamma, beta, dgamma, dbeta, 1, nullptr, scratch, B, HW, C, G, silu, stream);
+}
+
+extern "C" int lbmk_groupnorm_bwd_ex(const void* x, const void* dy, void* dx, const float* stats, const float* gamma,
+                                     const float* beta, void* dgamma, void* dbeta, int param_f32, const void* add,
+                                     float* scratch, int B, int HW, int C, int G, int silu, void* stream) {
   LBMK_REQUIRE(x && dy && dx && stats && scratch, "groupnorm_bwd: null pointer");
+  LBMK_REQUIRE(param_f32 == 0 || param_f32 == 1, "groupnorm_bwd: parameter dtype %d", param_f32);
+  LBMK_REQUIRE(!add || lbmk_aligned(add, 16), "groupnorm_bwd: misaligned residual gradient");
   LBMK_REQUIRE(lbmk_groupnorm_bwd_scratch_floats(B, HW, C, G) > 0 && B <= 65535, "groupnorm_bwd: B=%d HW=%d C=%d G=%d", B, HW, C, G);
   LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(dy, 16) && lbmk_aligned(dx, 16), "groupnorm_bwd: misaligned");
   hipStream_t s = (hipStream_t)stream;
@@ -716,16 +745,16 @@ extern "C" int lbmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
                        beta, partial, HW, C, G, rows_per_slab, nslab);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3((unsigned)(((int64_t)B * C + 31) / 32)), dim3(256), 0, s, partial, bc, B, C, nslab);
   const int nfin = C > B * G ? C : B * G;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, bc, gamma, dgamma, dbeta, gsum, B, C, G,
-                     1.0f / ((float)HW * (float)(C / G)));
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, bc, gamma, dgamma, dbeta, param_f32, gsum,
+                     B, C, G, 1.0f / ((float)HW * (float)(C / G)));
   const int64_t total8 = (int64_t)B * HW * nch;
   LBMK_REQUIRE((total8 + 255) / 256 < (1LL << 31), "groupnorm_bwd: grid");
   if (silu)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
-                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8);
+                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8, (const bf16_t*)add);
   else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x,
-                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8);
+                       (const bf16_t*)dy, (bf16_t*)dx, stats, gsum, gamma, beta, HW, C, G, total8, (const bf16_t*)add);
   return lbmk_check_launch("groupnorm_bwd");
 }
 
@@ -738,7 +767,16 @@ extern "C" int64_t lbmk_layernorm_bwd_scratch_floats(int rows, int C) {
 
 extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, float* dgamma_dbeta,
                                   float* scratch, int rows, int C, float eps, void* stream) {
+  return lbmk_layernorm_bwd_ex(x, dy, dx, gamma, dgamma_dbeta, dgamma_dbeta ? dgamma_dbeta + C : nullptr, 1, nullptr, scratch,
+                               rows, C, eps, stream);
+}
+
+extern "C" int lbmk_layernorm_bwd_ex(const void* x, const void* dy, void* dx, const float* gamma, void* dgamma, void* dbeta,
+                                     int param_f32, const void* add, float* scratch, int rows, int C, float eps, void* stream) {
   LBMK_REQUIRE(x && dy && dx && scratch, "layernorm_bwd: null pointer");
+  LBMK_REQUIRE(param_f32 == 0 || param_f32 == 1, "layernorm_bwd: parameter dtype %d", param_f32);
+  LBMK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "layernorm_bwd: dgamma and dbeta go together");
+  LBMK_REQUIRE(!add || lbmk_aligned(add, 16), "layernorm_bwd: misaligned residual gradient");
   const int64_t nfl = lbmk_layernorm_bwd_scratch_floats(rows, C);
   LBMK_REQUIRE(nfl > 0, "layernorm_bwd: rows=%d C=%d (C %% 8 == 0, C <= 2048)", rows, C);
   LBMK_REQUIRE(lbmk_aligned(x, 16) && lbmk_aligned(dy, 16) && lbmk_aligned(dx, 16), "layernorm_bwd: misaligned");
@@ -748,7 +786,7 @@ extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const
   const int nc = (C / 8 + 63) / 64;
   const size_t shm = (size_t)4 * 2 * C * sizeof(float);
 #define LN_BWD(NC) hipLaunchKernelGGL(ln_bwd_kernel<NC>, dim3(nblk), dim3(256), shm, s, (const bf16_t*)x, (const bf16_t*)dy, \
-                                      (bf16_t*)dx, gamma, scratch, rows, C, eps, rpb)
+                                      (bf16_t*)dx, gamma, scratch, rows, C, eps, rpb, (const bf16_t*)add)
   switch (nc) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;
@@ -757,9 +795,9 @@ extern "C" int lbmk_layernorm_bwd(const void* x, const void* dy, void* dx, const
   }
 #undef LN_BWD
   // block partials are [nblk][2][C]: row 0 dgamma, row 1 dbeta
-  if (dgamma_dbeta)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, scratch, (void*)dgamma_dbeta,
-                       (int64_t)2 * C, nblk, 1);
+  if (dgamma)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, s, scratch, dgamma, (int64_t)2 * C, nblk,
+                       param_f32, dbeta, (int64_t)C);
   return lbmk_check_launch("layernorm_bwd");
 }
 

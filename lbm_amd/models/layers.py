@@ -142,12 +142,18 @@ class HipGroupNorm(nn.GroupNorm, _Cached):
         return self._cached("a", (self.weight, self.bias),
                             lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
 
-    def forward(self, x, silu: bool = False):
+    def forward(self, x, silu: bool = False, passthrough: bool = False):
+        """``passthrough``: also return x for the residual link around the block -> (y, x).  On the training route that
+        second output is a node of the norm's autograd Function, so that both gradients of x meet in ONE backward
+        kernel (autograd.GroupNormFn); use it, not x, as the residual operand."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            from ..autograd import GroupNormFn
-            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+            from ..autograd import GRAD_FUSION, GroupNormFn
+            if passthrough and not GRAD_FUSION:
+                return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self, False), x
+            return GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, silu, self, passthrough)
         g, b = self.affine_f32()
-        return ops.groupnorm(x, g, b, self.num_groups, self.eps, silu)
+        y = ops.groupnorm(x, g, b, self.num_groups, self.eps, silu)
+        return (y, x) if passthrough else y
 
 
 class HipLayerNorm(nn.LayerNorm, _Cached):
@@ -155,12 +161,16 @@ class HipLayerNorm(nn.LayerNorm, _Cached):
         return self._cached("a", (self.weight, self.bias),
                             lambda: (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous()))
 
-    def forward(self, x):
+    def forward(self, x, passthrough: bool = False):
+        """``passthrough``: see HipGroupNorm.forward"""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            from ..autograd import LayerNormFn
-            return LayerNormFn.apply(x.contiguous(), self.weight, self.bias, self.eps)
+            from ..autograd import GRAD_FUSION, LayerNormFn
+            if passthrough and not GRAD_FUSION:
+                return LayerNormFn.apply(x.contiguous(), self.weight, self.bias, self.eps, self, False), x
+            return LayerNormFn.apply(x.contiguous(), self.weight, self.bias, self.eps, self, passthrough)
         g, b = self.affine_f32()
-        return ops.layernorm(x, g, b, self.eps)
+        y = ops.layernorm(x, g, b, self.eps)
+        return (y, x) if passthrough else y
 
 
 def training(*tensors_or_params) -> bool:

@@ -52,7 +52,7 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb_vec=None):
         """x: [B,H,W,Cin]; temb_vec: bf16 [B, Cout] = time_emb_proj(silu(temb)) (may be a strided view)."""
-        h = self.norm1(x, silu=True)
+        h, x = self.norm1(x, silu=True, passthrough=True)      # x: the residual link's view of the input
         h = self.conv1(h, rowvec=temb_vec)
         h = self.norm2(h, silu=True)
         res = x if self.conv_shortcut is None else self.conv_shortcut(x)
@@ -176,9 +176,12 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, h, ctx):
-        h = self.attn1(self.norm1(h), None, h)
-        h = self.attn2(self.norm2(h), ctx, h)
-        return self.ff(self.norm3(h), h)
+        xn, h = self.norm1(h, passthrough=True)      # h: the residual link's view of the block input (layers.HipLayerNorm)
+        h = self.attn1(xn, None, h)
+        xn, h = self.norm2(h, passthrough=True)
+        h = self.attn2(xn, ctx, h)
+        xn, h = self.norm3(h, passthrough=True)
+        return self.ff(xn, h)
 
 
 class Transformer2DModel(nn.Module):
@@ -199,7 +202,7 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, ctx):
         B, H, W, C = x.shape
-        h = self.norm(x)
+        h, x = self.norm(x, passthrough=True)
         # a 1x1 convolution on NHWC and a linear layer on tokens are the same GEMM
         h = self.proj_in(h)
         h = h.view(B, H * W, -1)

@@ -55,7 +55,8 @@ class VaeAttention(nn.Module, _Cached):
         N = H * W
         if N % 8:
             raise ValueError(f"VAE attention needs H*W % 8 == 0 (got {H}x{W})")
-        xn = self.group_norm(x).view(B, N, C)
+        xn, x = self.group_norm(x, passthrough=True)
+        xn = xn.view(B, N, C)
         D = C // self.heads
         if torch.is_grad_enabled() and (x.requires_grad or self.to_q.weight.requires_grad):
             from ...autograd import AttentionFn

@@ -947,8 +947,10 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torch.float32) -> torch.Tensor:
-    """x: bf16 [rows, N] -> [rows / rows_per_group, N] sums over each group of consecutive rows."""
+def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torch.float32,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: bf16 [rows, N] -> [rows / rows_per_group, N] sums over each group of consecutive rows.
+    ``out``: contiguous bf16 / f32 destination of that many elements (e.g. a bias's slot of a flat gradient buffer)."""
     _need_gpu(x)
     assert x.dtype == bf16 and x.dim() == 2 and x.stride(1) == 1
     rows, N = x.shape
@@ -957,7 +959,9 @@ def colsum(x: torch.Tensor, rows_per_group: Optional[int] = None, out_dtype=torc
     if nfl <= 0:
         raise _C.LbmkError(f"colsum: rows={rows} rows_per_group={rpg} N={N}")
     scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
-    out = torch.empty(rows // rpg, N, dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty(rows // rpg, N, dtype=out_dtype, device=x.device)
+    assert out.is_contiguous() and out.numel() == (rows // rpg) * N and out.dtype in (bf16, torch.float32)
     check(lib.lbmk_colsum(x.data_ptr(), out.data_ptr(), scratch.data_ptr(), rows, rpg, N, x.stride(0), _dt(out),
                           _stream()), "lbmk_colsum")
     return out
@@ -1082,9 +1086,37 @@ def groupnorm_train(x, gamma, beta, groups: int, eps: float, silu: bool):
     return y, buf[nfl - B * groups * 2:].view(B, groups, 2)
 
 
-def groupnorm_bwd(x, dy, stats, gamma, beta, groups: int, silu: bool):
-    """-> dx bf16, dgamma f32 [C], dbeta f32 [C]"""
+def _param_grad_outs(dg_out, db_out, Cc):
+    """checks a pair of caller-supplied dgamma / dbeta destinations; -> 1 (f32) / 0 (bf16)"""
+    assert dg_out is not None and db_out is not None and dg_out.dtype == db_out.dtype and dg_out.dtype in (bf16, torch.float32)
+    assert dg_out.is_contiguous() and db_out.is_contiguous() and dg_out.numel() == Cc and db_out.numel() == Cc
+    return 1 if dg_out.dtype == torch.float32 else 0
+
+
+def groupnorm_bwd(x, dy, stats, gamma, beta, groups: int, silu: bool, add=None, dg_out=None, db_out=None):
+    """-> dx bf16, dgamma f32 [C], dbeta f32 [C].  ``add``: bf16 tensor of x's shape added to dx (the gradient that
+    reached x through its residual link).  ``dg_out`` / ``db_out``: write dgamma / dbeta there, in their dtype (the
+    parameters' slots of a flat gradient buffer); the returned dgamma / dbeta are then None."""
     _need_gpu(x, dy, stats)
+    if add is not None or dg_out is not None:
+        assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous() and stats.is_contiguous()
+        assert add is None or (add.dtype == bf16 and add.is_contiguous() and add.shape == x.shape)
+        B, Cc = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        nfl = lib.lbmk_groupnorm_bwd_scratch_floats(B, HW, Cc, groups)
+        if nfl < 0:
+            raise _C.LbmkError(f"groupnorm_bwd: unsupported shape B={B} HW={HW} C={Cc} G={groups}")
+        scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        if dg_out is None:
+            dgb = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+            dg, db, pf, ret = dgb[0], dgb[1], 1, (dgb[0], dgb[1])
+        else:
+            dg, db, pf, ret = dg_out, db_out, _param_grad_outs(dg_out, db_out, Cc), (None, None)
+        check(lib.lbmk_groupnorm_bwd_ex(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), stats.data_ptr(), _ptr(gamma), _ptr(beta),
+                                        dg.data_ptr(), db.data_ptr(), pf, _ptr(add), scratch.data_ptr(), B, HW, Cc, groups,
+                                        1 if silu else 0, _stream()), "lbmk_groupnorm_bwd_ex")
+        return (dx, *ret)
     assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous() and stats.is_contiguous()
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
@@ -1101,9 +1133,27 @@ def groupnorm_bwd(x, dy, stats, gamma, beta, groups: int, silu: bool):
     return dx, dg, db
 
 
-def layernorm_bwd(x, dy, gamma, eps: float = 1e-5):
-    """-> dx bf16, dgamma f32 [C], dbeta f32 [C]"""
+def layernorm_bwd(x, dy, gamma, eps: float = 1e-5, add=None, dg_out=None, db_out=None):
+    """-> dx bf16, dgamma f32 [C], dbeta f32 [C]; ``add`` / ``dg_out`` / ``db_out`` as in groupnorm_bwd"""
     _need_gpu(x, dy)
+    if add is not None or dg_out is not None:
+        assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous()
+        assert add is None or (add.dtype == bf16 and add.is_contiguous() and add.shape == x.shape)
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        nfl = lib.lbmk_layernorm_bwd_scratch_floats(rows, Cc)
+        if nfl < 0:
+            raise _C.LbmkError(f"layernorm_bwd: unsupported shape rows={rows} C={Cc}")
+        scratch = torch.empty(nfl, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        if dg_out is None:
+            dgb = torch.empty(2, Cc, dtype=torch.float32, device=x.device)
+            dg, db, pf, ret = dgb[0], dgb[1], 1, (dgb[0], dgb[1])
+        else:
+            dg, db, pf, ret = dg_out, db_out, _param_grad_outs(dg_out, db_out, Cc), (None, None)
+        check(lib.lbmk_layernorm_bwd_ex(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(gamma), dg.data_ptr(), db.data_ptr(), pf,
+                                        _ptr(add), scratch.data_ptr(), rows, Cc, eps, _stream()), "lbmk_layernorm_bwd_ex")
+        return (dx, *ret)
     assert x.dtype == bf16 and dy.dtype == bf16 and x.is_contiguous() and dy.is_contiguous()
     Cc = x.shape[-1]
     rows = x.numel() // Cc

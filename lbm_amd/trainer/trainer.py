@@ -171,6 +171,18 @@ class GradSink:
 
         self.reducer.on_side_stream(run, reads)
 
+    def slots(self, params):
+        """Views of the gradient slots of ``params`` (each shaped like its parameter) for a producer kernel to write its
+        result straight into -- bias and norm scale / shift gradients, which autograd would otherwise add to the zeroed
+        slot with one small kernel each -- or None when one of them already holds a gradient this step (the caller then
+        hands its gradient to autograd, which accumulates).  Call ``commit`` once the producer has been launched."""
+        if any(id(p) not in self.slot or id(p) in self.reducer.written for p in params):
+            return None
+        return [self.group.grad[self.slot[id(p)][0]:self.slot[id(p)][0] + p.numel()].view_as(p) for p in params]
+
+    def commit(self, params):
+        self._mark(params, [True] * len(params))
+
     def _mark(self, params, fresh):
         for p, f in zip(params, fresh):
             if f:
