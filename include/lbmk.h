@@ -295,6 +295,14 @@ int lbmk_pack_conv_weight(const void* w, void* out, int N, int Cin, int KH, int 
 int lbmk_gemm_tn(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
                  int splits, int out_f32, void* stream);
 
+/* Input gradient of a linear layer on the UNTRANSPOSED weight (torch autograd of nn.Linear in diffusers' Attention /
+ * FeedForward under the reference's trainer, src/lbm/trainer/trainer.py:217-240: dX = dY . W):
+ * out[m][k] = sum_n a[m][n] * b[n][k];  a = dY bf16 [M][lda], b = W bf16 [N][ldb] (the parameter as stored), out bf16
+ * [M][ldo] (splits == 1) or f32 partials [splits][M][ldo] over equal chunks of n, to be summed by lbmk_sum_partials.
+ * N, K multiples of 8.  No transposed copy of the weight is made (the weights change every optimisation step). */
+int lbmk_gemm_nn(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
+                 int splits, int out_f32, void* stream);
+
 /* out[i] = sum_s partial[s][i]: the split-K partial products of a weight-gradient GEMM (f32 [nseg][n],
  * summed in a fixed order) -> bf16 (out_dtype 0) or f32 (1).  Part of the dW = dY^T X path above. */
 int lbmk_sum_partials(const float* partial, void* out, int64_t n, int nseg, int out_dtype, void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "lbmk_sum_partials": (i32, [vp, vp, i64, i32, i32, vp]),
     "lbmk_splitk_finish": (i32, [vp, i32, i64, vp, vp, i32, vp, i32, i32, i32, vp]),
     "lbmk_gemm_tn": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "lbmk_gemm_nn": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lbmk_lpips_prep": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "lbmk_lpips_prep_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),

@@ -93,9 +93,12 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape
         dx = dw = db = dres = drv = None
         if ctx.needs_input_grad[0]:
-            dx = _linear_maybe_splitk(dy2, ctx.mod.packed_t(), None)
-            if dx is None:
-                dx = ops.linear(dy2, ctx.mod.packed_t())
+            if ops.gemm_nn_ok(dy2, weight):
+                dx = ops.gemm_nn(dy2, weight)                   # reads the parameter as stored: no W^T copy per step
+            else:
+                dx = _linear_maybe_splitk(dy2, ctx.mod.packed_t(), None)
+                if dx is None:
+                    dx = ops.linear(dy2, ctx.mod.packed_t())
             dx = dx[:, :K].reshape(x.shape)
         if ctx.needs_input_grad[1]:
             xc = x2.contiguous() if x2.stride(1) != 1 else x2
@@ -374,7 +377,12 @@ class SelfAttnQKVFn(torch.autograd.Function):
         d2, x2 = _rows(dqkv), _rows(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(d2, ctx.mod.packed_qkv_t())[:, :x.shape[-1]].reshape(x.shape)
+            stack = ctx.mod._qkv_stack()[0]
+            is_view = stack.data_ptr() in (mod_w.data_ptr() for mod_w in (ctx.mod.to_q.weight, ctx.mod.to_k.weight, ctx.mod.to_v.weight))
+            if is_view and ops.gemm_nn_ok(d2, stack):    # (a stack that had to be concatenated is no cheaper than W^T)
+                dx = ops.gemm_nn(d2, stack).reshape(x.shape)
+            else:
+                dx = ops.linear(d2, ctx.mod.packed_qkv_t())[:, :x.shape[-1]].reshape(x.shape)
         dws = [None, None, None]
         mod = ctx.mod
         ws = [mod.to_q.weight, mod.to_k.weight, mod.to_v.weight]

@@ -135,7 +135,154 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Input-gradient GEMM on the untransposed weight:  out[m][k] = sum_n A[m][n] * B[n][k]
+// (A = dY [M][N] row-major: the reduction index n is contiguous, the usual A operand; B = W [N][K] row-major, the
+// parameter itself: the reduction index is its ROW, so its tile is staged in the natural [n][128 columns] layout and
+// read with the transposing LDS read, exactly like the operands of the weight-gradient kernel above).  No W^T copy.
+// Workgroup = 4 waves = a 128 (m) x 128 (k) output tile, 64 x 64 per wave; 64 of n per stage, two stage buffers.
+// blockIdx.z splits the n range (f32 partials [split][M][K], summed in a fixed order by lbmk_sum_partials).
+constexpr int NN_BM = 128, NN_BK = 128, NN_NS = 64;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         void* __restrict__ out, int M, int N, int K, int lda, int ldb,
+                                                         int ldo, int n_chunk, int tiles_k) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TN_TILE];   // [buffer][A tile 128 x 128 B | B tile 64 x 256 B]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wk = wave & 1;
+  const int tile_m = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_m * tiles_k;
+  const int m0 = tile_m * NN_BM, k0 = tile_k * NN_BK;
+  const int z = blockIdx.z;
+  const int n_begin = z * n_chunk, n_end = min(n_begin + n_chunk, N);
+
+  // A staging: chunk idx = i * 256 + t -> (row = idx >> 3, slot = idx & 7); LDS image lane-linear, the 16-byte slots of
+  // a row XOR-swizzled on the source side and on the read address (conflict-free ds_read_b128 of 16 rows x one chunk)
+  unsigned a_off[4];
+  int a_col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = i * 256 + t, row = idx >> 3, slot = idx & 7;
+    const int ch = slot ^ ((row >> 1) & 7);
+    a_col[i] = ch * 8;
+    a_off[i] = (m0 + row < M) ? (unsigned)(row * lda + ch * 8) * 2u : TN_OOB;
+  }
+  // B staging as in gemm_tn_kernel: (row = reduction index, 16 slots of 8 columns)
+  const int slot = lane & 15, rsub = lane >> 4;
+  unsigned b_off[4];
+  int srow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 16 + wave * 4 + rsub;
+    const int ch = slot ^ tn_swz(row);
+    srow[i] = row;
+    b_off[i] = (k0 + ch * 8 < K) ? (unsigned)(row * ldb + k0 + ch * 8) * 2u : TN_OOB;
+  }
+  const bf16_t* a_base = A + (int64_t)m0 * lda + n_begin;
+  const bf16_t* b_base = B + (int64_t)n_begin * ldb;
+  const int rows_a = min(NN_BM, M - m0);
+  const int64_t a_span = ((int64_t)(rows_a - 1) * lda + (n_end - n_begin)) * 2;
+  const int64_t b_span = ((int64_t)(n_end - n_begin - 1) * ldb + K) * 2;
+  const int a_bytes = (int)(a_span > 0x7fffffff ? 0x7fffffff : a_span), b_bytes = (int)(b_span > 0x7fffffff ? 0x7fffffff : b_span);
+
+  auto stage = [&](int ns, char* buf) __attribute__((always_inline)) {
+    const int nb = n_begin + ns * NN_NS;
+    const unsigned so_a = (unsigned)(ns * NN_NS) * 2u, so_b = (unsigned)(ns * NN_NS) * (unsigned)ldb * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool col_ok = nb + a_col[i] < n_end;         // N % 8 == 0: a chunk is inside or outside as a whole
+      buffer_lds16(a_base, a_bytes, (col_ok && a_off[i] != TN_OOB) ? a_off[i] + so_a : TN_OOB, 0, buf + (i * 256 + wave * 64) * 16);
+      const bool row_ok = nb + srow[i] < n_end;
+      buffer_lds16(b_base, b_bytes, (row_ok && b_off[i] != TN_OOB) ? b_off[i] + so_b : TN_OOB, 0,
+                   buf + TN_TILE + (i * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x4 acc[4][4];   // [k fragment][m fragment]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int l = lane & 15, g = lane >> 4;
+  auto compute = [&](const char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                     // dY: row m, reduction elements 32 ks + 8 g .. + 7
+        const int r = wm * 64 + 16 * j + l;
+        fa[j] = *(const bf16x8*)(buf + r * 128 + (((4 * ks + g) ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[i] = tn_frag(buf + TN_TILE, 32 * ks + 8 * g, wk * 4 + i, l);   // W: columns k
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nns = (n_end - n_begin + NN_NS - 1) / NN_NS;
+  stage(0, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ns = 0; ns < nns; ++ns) {
+    if (ns + 1 < nns) stage(ns + 1, smem + ((ns + 1) & 1) * 2 * TN_TILE);
+    compute(smem + (ns & 1) * 2 * TN_TILE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // lane holds out[m = m0 + 64 wm + 16 j + l][k = k0 + 64 wk + 16 i + 4 g .. +3]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + 16 * j + l;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + wk * 64 + 16 * i + 4 * g;
+      if (k >= K) continue;
+      const int64_t at = ((int64_t)z * M + m) * ldo + k;
+      if (OUT_F32) *(f32x4*)((float*)out + at) = acc[i][j];
+      else {
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.v[e] = f2bf(acc[i][j][e]);
+        *(u16x4*)((bf16_t*)out + at) = o;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int lbmk_gemm_nn(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
+                            int splits, int out_f32, void* stream) {
+  LBMK_REQUIRE(a && b && out, "gemm_nn: null pointer");
+  LBMK_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, "gemm_nn: M=%d N=%d K=%d (N, K multiples of 8)", M, N, K);
+  LBMK_REQUIRE(lda >= N && ldb >= K && ldo >= K && lda % 8 == 0 && ldb % 8 == 0 && ldo % 4 == 0, "gemm_nn: leading dims");
+  LBMK_REQUIRE(splits >= 1 && splits <= 65535 && (splits == 1 || out_f32), "gemm_nn: %d splits need f32 partials", splits);
+  LBMK_REQUIRE(lbmk_aligned(a, 16) && lbmk_aligned(b, 16) && lbmk_aligned(out, out_f32 ? 16 : 8), "gemm_nn: misaligned");
+  int n_chunk = (N + splits - 1) / splits;
+  n_chunk = (n_chunk + NN_NS - 1) / NN_NS * NN_NS;
+  LBMK_REQUIRE((int64_t)(splits - 1) * n_chunk < N, "gemm_nn: %d splits of %d leave an empty split", splits, n_chunk);
+  // 32-bit byte offsets inside one tile's window of A (128 rows) and one split's window of B
+  LBMK_REQUIRE((int64_t)(NN_BM + 1) * lda * 2 < (1LL << 31) && (int64_t)(n_chunk + NN_NS) * ldb * 2 < (1LL << 31),
+               "gemm_nn: operand window overflows 32-bit offsets");
+  const int64_t tiles_m = (M + NN_BM - 1) / NN_BM, tiles_k = (K + NN_BK - 1) / NN_BK;
+  LBMK_REQUIRE(tiles_m * tiles_k < (1LL << 31), "gemm_nn: grid");
+  dim3 grid((unsigned)(tiles_m * tiles_k), 1, (unsigned)splits);
+  if (out_f32)
+    hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, out,
+                       M, N, K, lda, ldb, ldo, n_chunk, (int)tiles_k);
+  else
+    hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, out,
+                       M, N, K, lda, ldb, ldo, n_chunk, (int)tiles_k);
+  return lbmk_check_launch("gemm_nn");
+}
 
 extern "C" int lbmk_gemm_tn(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
                             int splits, int out_f32, void* stream) {

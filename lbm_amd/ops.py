@@ -1009,6 +1009,41 @@ def _pad_rows8(x: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(x, (0, 0, 0, 8 - r % 8))
 
 
+_GEMM_NN = os.environ.get("LBM_NO_GEMM_NN") is None      # LBM_NO_GEMM_NN=1: input gradients through W^T copies (A/B runs)
+
+
+def gemm_nn_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """operands the untransposed-weight input-gradient kernel takes: bf16, unit column stride, 16-byte aligned rows"""
+    return (_GEMM_NN and a.is_cuda and a.dtype == bf16 and w.dtype == bf16 and a.dim() == 2 and w.dim() == 2
+            and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[0] and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+            and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and 129 * a.stride(0) * 2 < (1 << 31))
+
+
+def gemm_nn(a: torch.Tensor, w: torch.Tensor, splits: Optional[int] = None) -> torch.Tensor:
+    """out[m][k] = sum_n a[m][n] * w[n][k]: the input gradient dX = dY . W of a linear layer, read from the parameter
+    as it is stored ([N, K] row-major) -- no W^T copy.  a bf16 [M, N], w bf16 [N, K] -> bf16 [M, K].
+    Few output tiles: the n range is split across workgroups, f32 partials summed in a fixed order."""
+    _need_gpu(a, w)
+    assert gemm_nn_ok(a, w)
+    M, N = a.shape
+    K = w.shape[1]
+    tiles = ((M + 127) // 128) * ((K + 127) // 128)
+    if splits is None:
+        splits = 1 if tiles >= 200 else max(1, min(-(-400 // tiles), N // 512))
+    chunk = -(-(-(-N // splits)) // 64) * 64
+    splits = -(-N // chunk)
+    if splits == 1:
+        out = torch.empty(M, K, dtype=bf16, device=a.device)
+        check(lib.lbmk_gemm_nn(a.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), w.stride(0), K, 1, 0,
+                               _stream()), "lbmk_gemm_nn")
+        return out
+    part = torch.empty(splits, M, K, dtype=torch.float32, device=a.device)
+    check(lib.lbmk_gemm_nn(a.data_ptr(), w.data_ptr(), part.data_ptr(), M, N, K, a.stride(0), w.stride(0), K, splits, 1,
+                           _stream()), "lbmk_gemm_nn")
+    return sum_partials(part, bf16)
+
+
 def sum_partials(part: torch.Tensor, out_dtype=torch.float32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """f32 [S, ...] -> sum over S in a fixed order, as bf16 or f32."""
     _need_gpu(part)

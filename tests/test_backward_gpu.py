@@ -636,6 +636,26 @@ def test_unet_sd15_style_gradients(cuda, mode):
         assert ctx_g.grad is not None and rel_l2(ctx_g.grad, ctx_r.grad) < 6e-2
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(1000, 320, 200, None), (2048, 1280, 640, 1), (2048, 10240, 1280, None), (2048, 1280, 640, 3),
+                                          (4104, 136, 72, None), (64, 128, 128, None), (8192, 2560, 640, None), (333, 1288, 24, 4)])
+def test_gemm_nn_untransposed_weight(cuda, gen, M, N, K, splits):
+    """dX = dY W straight from the parameter as stored ([N, K] row-major, transposing LDS reads for the weight tile):
+    ragged tiles in M and K, reduction lengths that are not whole stages, forced and automatic splits of the reduction,
+    a strided dY, and a fixed summation order"""
+    from lbm_amd import ops
+    a = torch.empty(M, N + 8, dtype=BF, device=cuda)[:, :N].copy_(randbf(gen, M, N).to(cuda))     # row stride N + 8
+    w = (randbf(gen, N, K) * 0.1).to(BF).to(cuda)
+    ref = a.float().cpu() @ w.float().cpu()
+    assert ops.gemm_nn_ok(a, w)
+    out = ops.gemm_nn(a, w, splits=splits)
+    assert out.shape == (M, K) and out.dtype == BF and rel_l2(out, ref) < 4e-3
+    assert torch.equal(ops.gemm_nn(a, w, splits=splits), out)
+    if splits is None:
+        # same product as the forward GEMM on a W^T copy (different summation order: equal to rounding)
+        alt = ops.linear(a, ops.pack_linear_weight(w.t().contiguous(), None))
+        assert rel_l2(out, alt) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(1000, 320, 200, None), (2048, 1280, 640, 1), (2048, 1280, 640, 3), (4096, 136, 72, None),
                                           (64, 128, 128, None), (8192, 640, 2560, None), (333 * 8, 24, 1288, 4)])
 def test_gemm_tn_untransposed_operands(cuda, gen, M, N, K, splits):
