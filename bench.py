@@ -116,13 +116,16 @@ def measured_gemm_ceiling(device, reps=5):
             "shape": "16384 x 16384 x 8192 bf16 NT product, random N(0,1) operands, lbmk_igemm", "ms": round(ms, 3), "reps": reps}
 
 
-PMC_TRAFFIC_FILES = ("profiles/r02_pmc_igemm_step_traffic_v2.json", "profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
+PMC_TRAFFIC_FILES = ("profiles/r03_pmc_igemm_step_traffic.json", "profiles/r02_pmc_igemm_step_traffic_v2.json",
+                     "profiles/r02_pmc_igemm_step_traffic.json", "profiles/r01_pmc_igemm_step_traffic.json")
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, launches):
     """HBM bytes per igemm launch, REPLAYED from the newest committed record of separate rocprofv3 --pmc passes over this
-    same command (hardware counters cannot be read from inside the run): (bytes, source file), or (None, None) when the
-    workload differs from the profiled one or no record exists."""
+    same command (hardware counters cannot be read from inside the run): the record's bytes per STEP over the ``launches``
+    of the one-stream pass the roofline is measured on (the two-stream step of the PMC passes cuts the same bytes into
+    about twice as many launches).  (bytes, source file), or (None, None) when the workload differs from the profiled one
+    or no record exists."""
     for rel in PMC_TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -130,6 +133,8 @@ def pmc_traffic(args):
         except OSError:
             continue
         if rec.get("workload") == {"res": args.res, "batch": args.batch, "nfe": args.nfe}:
+            if "traffic_bytes_per_step" in rec:
+                return round(rec["traffic_bytes_per_step"] / launches), rel
             return round(rec["traffic_bytes_per_launch"]), rel
     return None, None
 
@@ -398,9 +403,9 @@ def main():
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv/linear, all tile shapes)",
                     "achieved": round(tf, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
-                    "executed": round(prof["executed"] / (prof["ms"] * 1e-3) / 1e12, 2), "traffic": pmc_traffic(args)[0],
-                    "traffic_source": (f"replayed constant from {pmc_traffic(args)[1]} (separate rocprofv3 --pmc passes over "
-                                       "this command; not measured in this run)") if pmc_traffic(args)[1] else None,
+                    "executed": round(prof["executed"] / (prof["ms"] * 1e-3) / 1e12, 2), "traffic": pmc_traffic(args, prof["launches"])[0],
+                    "traffic_source": (f"replayed constant from {pmc_traffic(args, prof['launches'])[1]} (separate rocprofv3 --pmc "
+                                       "passes over this command; not measured in this run)") if pmc_traffic(args, prof["launches"])[1] else None,
                     "launches": prof["launches"], "avg_launch_ms": round(prof["ms"] / prof["launches"], 4),
                     "flops_per_launch": prof["flops"] / prof["launches"],
                     "measured_ceiling": ceiling,
