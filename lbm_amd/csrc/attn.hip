@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256, 3) void flash_fwd_d64_kernel(
 
 // Same algorithm for any head_dim that is a multiple of 8 (the SD1.5-style UNet has 40 / 80 / 160):
 // the K image is [key][ceil16(D)] with the pad chunk read from the zero page, O^T has ceil(D/32) tiles.
-template <int DH>
+// FAST: as in the head_dim-64 kernel (prescaled q, the lagging maximum subtracted as the score product's C operand).
+template <int DH, bool FAST>
 __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
     bf16_t* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, int64_t sq,
@@ -303,8 +304,13 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
     const bf16_t* qp = Q + (int64_t)qr * ldq + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (16 * ks + 8 * h + 8 <= DH) qf[ks] = *(const bf16x8*)(qp + 16 * ks);
-      else {
+      if (16 * ks + 8 * h + 8 <= DH) {
+        qf[ks] = *(const bf16x8*)(qp + 16 * ks);
+        if (FAST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)((float)qf[ks][e] * scale_log2e);
+        }
+      } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)0.f;
       }
@@ -317,6 +323,11 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  f32x16 negm;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+  float c_m = 0.f;
+  constexpr float LAG = 10.f;
 
   const int slot = t & 7, rsub = t >> 3;
   const int cs = slot ^ ((rsub >> 1) & 7);
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+      for (int e = 0; e < 16; ++e) s[kt][e] = FAST ? negm[e] : 0.f;
       const char* krow = sK + (32 * kt + r) * KROW + h * 16;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -383,26 +394,54 @@ __global__ __launch_bounds__(256) void flash_fwd_gen_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some row's maximum moved: rescale
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-      m_run = m_new;
-    }
     float psum = 0.f;
     bf16x8 pf[2][2];
+    if (FAST) {
+      if (__builtin_amdgcn_ballot_w64(mx + c_m - LAG > m_run) != 0) {   // some row outgrew m by more than 2^LAG (or first tile)
+        const float m_new = fmaxf(m_run, mx + c_m);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+        for (int i = 0; i < DT; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s[kt][e] * scale_log2e - m_new);
-        psum += pv;
-        pf[kt][e >> 3][e & 7] = (__bf16)pv;
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        const float d = m_new - c_m;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[kt][e] -= d;
+        m_run = c_m = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[e] = -m_new;
       }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(s[kt][e]);
+          psum += pv;
+          pf[kt][e >> 3][e & 7] = (__bf16)pv;
+        }
+    } else {
+      const float m_new = fmaxf(m_run, mx * scale_log2e);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some row's maximum moved: rescale
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        m_run = m_new;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(s[kt][e] * scale_log2e - m_new);
+          psum += pv;
+          pf[kt][e >> 3][e & 7] = (__bf16)pv;
+        }
+    }
     l_run += psum;
     // lane pair exchange: 8 consecutive keys per lane and 16-key step (see the head_dim-64 kernel)
 #pragma unroll
@@ -556,20 +595,21 @@ extern "C" int lbmk_flash_attn_fwd(const void* q, const void* k, const void* vt,
   hipStream_t s = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
   static const bool no_fast = getenv("LBMK_NO_FLASH_FAST") != nullptr;
+  const bool fast = !lse && !no_fast;
 #define FA_ARGS (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)o, Nq, Nk, ldq, ldk, ldvt, ldo, sq, sk, svt, so, sl2, lse
   switch (Dh) {
     case 64:
       // the log-sum-exp rows feed the backward kernels, which recompute the scores from the unscaled q: keep that
       // pass's arithmetic; LBMK_NO_FLASH_FAST=1 does the same for inference (same-box A/B runs)
-      if (lse || no_fast) hipLaunchKernelGGL(flash_fwd_d64_kernel<false>, grid, dim3(256), 0, s, FA_ARGS);
+      if (!fast) hipLaunchKernelGGL(flash_fwd_d64_kernel<false>, grid, dim3(256), 0, s, FA_ARGS);
       else hipLaunchKernelGGL(flash_fwd_d64_kernel<true>, grid, dim3(256), 0, s, FA_ARGS);
       break;
-    case 8: hipLaunchKernelGGL(flash_fwd_gen_kernel<8>, grid, dim3(256), 0, s, FA_ARGS); break;
-    case 16: hipLaunchKernelGGL(flash_fwd_gen_kernel<16>, grid, dim3(256), 0, s, FA_ARGS); break;
-    case 32: hipLaunchKernelGGL(flash_fwd_gen_kernel<32>, grid, dim3(256), 0, s, FA_ARGS); break;
-    case 40: hipLaunchKernelGGL(flash_fwd_gen_kernel<40>, grid, dim3(256), 0, s, FA_ARGS); break;
-    case 80: hipLaunchKernelGGL(flash_fwd_gen_kernel<80>, grid, dim3(256), 0, s, FA_ARGS); break;
-    case 160: hipLaunchKernelGGL(flash_fwd_gen_kernel<160>, grid, dim3(256), 0, s, FA_ARGS); break;
+    case 8: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<8, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<8, false>), grid, dim3(256), 0, s, FA_ARGS); break;
+    case 16: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<16, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<16, false>), grid, dim3(256), 0, s, FA_ARGS); break;
+    case 32: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<32, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<32, false>), grid, dim3(256), 0, s, FA_ARGS); break;
+    case 40: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<40, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<40, false>), grid, dim3(256), 0, s, FA_ARGS); break;
+    case 80: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<80, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<80, false>), grid, dim3(256), 0, s, FA_ARGS); break;
+    case 160: if (fast) hipLaunchKernelGGL((flash_fwd_gen_kernel<160, true>), grid, dim3(256), 0, s, FA_ARGS); else hipLaunchKernelGGL((flash_fwd_gen_kernel<160, false>), grid, dim3(256), 0, s, FA_ARGS); break;
   }
 #undef FA_ARGS
   return lbmk_check_launch("flash_attn");
