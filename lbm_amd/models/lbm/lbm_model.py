@@ -184,33 +184,38 @@ class LBMModel(BaseModel):
         return PixelLossFn.apply(decoded.contiguous(), model_input, valid_mask, self.pixel_loss_type == "l1", clamp)
 
     def _get_conditioning(self, batch: Dict[str, Any], ucg_keys: List[str] = None, set_ucg_rate_zero=False, *args, **kwargs):
-        if self.conditioner is not None:
-            conditioning = self.conditioner(batch, ucg_keys=ucg_keys, set_ucg_rate_zero=set_ucg_rate_zero, vae=self.vae,
-                                            *args, **kwargs)
-            if conditioning and "cond" in conditioning:
-                crossattn = conditioning["cond"].get("crossattn")
-                if crossattn is not None and self.config.lighting_condition_weight != 1.0:
-                    conditioning["cond"]["crossattn"] = crossattn * self.config.lighting_condition_weight
-                concat = conditioning["cond"].get("concat")
-                if concat is not None and self.config.concat_condition_weight != 1.0:
-                    conditioning["cond"]["concat"] = concat * self.config.concat_condition_weight
-            return conditioning
-        return None
+        """Conditioner outputs with the two per-kind weights of the config applied (lbm_model.py:251-275): cross-attention
+        tokens times ``lighting_condition_weight``, concatenated maps times ``concat_condition_weight`` (a weight of 1 leaves
+        the tensor untouched, so no multiplication and no new tensor)."""
+        if self.conditioner is None:
+            return None
+        out = self.conditioner(batch, *args, ucg_keys=ucg_keys, set_ucg_rate_zero=set_ucg_rate_zero, vae=self.vae, **kwargs)
+        cond = out.get("cond") if out else None
+        if cond is not None:
+            for kind, weight in (("crossattn", self.config.lighting_condition_weight),
+                                 ("concat", self.config.concat_condition_weight)):
+                if cond.get(kind) is not None and weight != 1.0:
+                    cond[kind] = cond[kind] * weight
+        return out
 
     def _timestep_sampling(self, n_samples=1, device="cpu"):
-        """Host-side draws in the reference's order and from the same generators (lbm_model.py:277-291)."""
+        """One training timestep per sample, drawn on the HOST from the generators the reference uses, in its order
+        (lbm_model.py:277-291): torch's CPU generator for "uniform" (one randint) and "log_normal" (one normal), numpy's
+        global generator for "custom_timesteps" (one choice with the configured probabilities)."""
+        mode = self.timestep_sampling
+        if mode == "custom_timesteps":
+            picks = np.random.choice(len(self.selected_timesteps), n_samples, p=self.prob)
+            return torch.tensor(self.selected_timesteps, device=device, dtype=torch.long)[picks]
         sched = self.training_noise_scheduler
-        if self.timestep_sampling == "uniform":
-            idx = torch.randint(0, sched.config.num_train_timesteps, (n_samples,), device="cpu")
-            return sched.timesteps[idx].to(device=device)
-        elif self.timestep_sampling == "log_normal":
-            u = torch.normal(mean=self.logit_mean, std=self.logit_std, size=(n_samples,), device="cpu")
-            u = torch.nn.functional.sigmoid(u)
-            indices = (u * sched.config.num_train_timesteps).long()
-            return sched.timesteps[indices].to(device=device)
-        elif self.timestep_sampling == "custom_timesteps":
-            idx = np.random.choice(len(self.selected_timesteps), n_samples, p=self.prob)
-            return torch.tensor(self.selected_timesteps, device=device, dtype=torch.long)[idx]
+        n_train = sched.config.num_train_timesteps
+        if mode == "uniform":
+            picks = torch.randint(0, n_train, (n_samples,), device="cpu")
+        elif mode == "log_normal":
+            logits = torch.normal(mean=self.logit_mean, std=self.logit_std, size=(n_samples,), device="cpu")
+            picks = (torch.sigmoid(logits) * n_train).long()
+        else:
+            return None          # LBMConfig validates the mode; the reference falls through the same way
+        return sched.timesteps[picks].to(device=device)
 
     def _predicted_x_0(self, model_output, sample, sigmas=None):
         return ops.axpy_rows(sample.contiguous(), model_output.contiguous(), -sigmas.reshape(-1))
