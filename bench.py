@@ -193,30 +193,40 @@ def extra_fp32(device, rank, world, dist, res, batch, steps):
             "tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / world / 157.3, 4)}
 
 
-def extra_training(model, device, rank, world, dist, res, batch, steps):
+def extra_training(model, device, rank, world, dist, batch, steps, resolutions=(512, 1024)):
     """bridge-matching training step: two frozen VAE encodes, interpolant, UNet forward + backward, latent loss,
-    gradient exchange over RCCL when world > 1, fused AdamW.  7.31 TFLOP per 512x512 sample (2 * 1.117 + 3 * 1.693)."""
+    gradient exchange over RCCL when world > 1, fused AdamW.  7.31 TFLOP per 512x512 sample (2 * 1.117 + 3 * 1.693).
+    One pipeline, measured at each resolution: 512x512 is the size the reference's training configs use
+    (examples/training/config/*.yaml: image_size 512); 1024x1024 shows the same kernels on four times the rows per
+    GEMM (the 512x512 step's token matrices have 2048 / 8192 rows)."""
     from lbm_amd.trainer import TrainingConfig, TrainingPipeline
     model.train()
     model.vae.freeze()
     pipe = TrainingPipeline(model, TrainingConfig(learning_rate=4e-5, optimizer_name="AdamW", trainable_params=["denoiser.*"]),
                             dist=dist)
     pipe.configure_optimizers()
-    g = torch.Generator().manual_seed(4242 + rank)
-    batch_d = {"source_image": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device),
-               "source_image_paste": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device)}
-    for _ in range(2):
-        loss = pipe.fit_step(batch_d)["loss"]
-    el = _timed_steps(lambda: pipe.fit_step(batch_d), steps, dist, device)
-    assert bool(torch.isfinite(loss))
-    sps = batch * world * steps / el
-    enc, unet, _ = FLOPS_T[res]
-    tf = sps * (2 * enc + 3 * unet)
-    return {"workload": f"training step {res}x{res}, batch {batch}/GPU x{world}: 2 frozen VAE encodes + UNet fwd/bwd + latent loss + "
+    out = {}
+    for res in resolutions:
+        g = torch.Generator().manual_seed(4242 + rank)
+        batch_d = {"source_image": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device),
+                   "source_image_paste": (torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(BF).to(device)}
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(2):
+            loss = pipe.fit_step(batch_d)["loss"]
+        el = _timed_steps(lambda: pipe.fit_step(batch_d), steps, dist, device)
+        assert bool(torch.isfinite(loss))
+        sps = batch * world * steps / el
+        enc, unet, _ = FLOPS_T[res]
+        tf = sps * (2 * enc + 3 * unet)
+        out[f"train_{res}_b{batch}"] = {
+            "workload": f"training step {res}x{res}, batch {batch}/GPU x{world}: 2 frozen VAE encodes + UNet fwd/bwd + latent loss + "
                         f"{pipe.reducer.mode if dist is not None else 'no'} gradient exchange + AdamW",
             "value": round(sps, 3), "unit": "samples/s", "ms_per_step": round(el / steps * 1e3, 1), "steps": steps,
             "tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / world / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+        del batch_d
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_ranks(n, argv, timeout_s=None):
@@ -434,10 +444,14 @@ def main():
         for name, fn in (("c1_512_b1_fp32", lambda: extra_fp32(device, rank, world, dist, 512, 1, 2)),
                          ("nfe4_1024_b8", lambda: extra_inference(model, device, rank, world, dist, 1024, 8, 4, 2)),
                          ("res2048_b8", lambda: extra_inference(model, device, rank, world, dist, 2048, 8, 1, 1)),
-                         ("train_512_b8", lambda: extra_training(model, device, rank, world, dist, 512, 8, 3))):
+                         ("train_b8", lambda: extra_training(model, device, rank, world, dist, 8, 3))):
             state["in_flight"] = name
             try:
-                state["extra"][name] = fn()
+                rec = fn()
+                if name == "train_b8":
+                    state["extra"].update(rec)          # train_512_b8, train_1024_b8
+                else:
+                    state["extra"][name] = rec
             except Exception as err:          # an extra must never cost the headline line
                 state["extra"][name] = {"error": f"{type(err).__name__}: {err}"[:300]}
                 break

@@ -42,6 +42,11 @@ import os
 GRAD_FUSION = os.environ.get("LBM_NO_GRAD_FUSION") is None
 
 
+# bytes a transposed operand of the convolution weight gradient may span (32-bit byte offsets in the GEMM kernel); tests
+# lower it to exercise the grouping
+WGRAD_WINDOW_BYTES = (1 << 31) - 1
+
+
 def _param_slots(*params):
     """(sink, slot views) when the gradients of these (small) parameters can be written straight into the trainer's flat
     gradient buffer by the kernel that produces them, else (None, None)"""
@@ -158,8 +163,20 @@ class Conv2dFn(torch.autograd.Function):
                 dx = dx[..., :Cs].contiguous() if dx.shape[-1] > Cs else torch.nn.functional.pad(dx, (0, Cs - dx.shape[-1]))
         if ctx.needs_input_grad[1]:
             def wgrad():
-                col_t = ops.im2col_t(x, cin_p, KH, KW, stride, pad, up2, (OH, OW))     # [KH*KW*cin_p, M]
-                dwk = ops.gemm_tn_t(ops.transpose(dy2), col_t, out_dtype=torch.float32)   # [npad, KH*KW*cin_p]
+                # the transposed operands are [rows][M] matrices addressed with 32-bit byte offsets: beyond 2 GiB (8 images
+                # of 128 x 128 latent pixels times 8640 im2col rows) the images are processed in groups, partial sums in f32
+                K9, per = KH * KW * cin_p, OH * OW
+                max_cols = WGRAD_WINDOW_BYTES // (2 * max(K9, npad)) // 8 * 8
+                nb = min(B, max_cols // per)
+                if nb < 1:
+                    raise NotImplementedError(f"convolution weight gradient: one image's {per} output pixels x {K9} im2col rows "
+                                              "exceed the 2 GiB operand window")
+                dwk = None
+                for b0 in range(0, B, nb):
+                    b1 = min(B, b0 + nb)
+                    col_t = ops.im2col_t(x[b0:b1], cin_p, KH, KW, stride, pad, up2, (OH, OW))       # [KH*KW*cin_p, rows of the group]
+                    part = ops.gemm_tn_t(ops.transpose(dy2[b0 * per:b1 * per]), col_t, out_dtype=torch.float32)   # [npad, KH*KW*cin_p]
+                    dwk = part if dwk is None else dwk.add_(part)
                 return dwk[:N].view(N, KH * KW, cin_p)[:, :, :Cin].permute(0, 2, 1)       # [N, Cin, KH*KW] strided view
             sink = _grad_sink(ctx.mod.weight)
             if sink is not None:

@@ -636,6 +636,33 @@ def test_unet_sd15_style_gradients(cuda, mode):
         assert ctx_g.grad is not None and rel_l2(ctx_g.grad, ctx_r.grad) < 6e-2
 
 
+def test_conv_weight_gradient_in_image_groups(cuda, gen):
+    """the transposed operands of a convolution's weight gradient are addressed with 32-bit byte offsets: past 2 GiB
+    (a 1024x1024 batch-8 training step) the images are processed in groups with f32 partial sums.  Forced here by
+    lowering the window: same gradient as in one piece."""
+    from lbm_amd import autograd
+    from lbm_amd.models.layers import HipConv2d
+    torch.manual_seed(3)
+    conv = HipConv2d(64, 72, 3, padding=1).to(BF).to(cuda)
+    x = randbf(gen, 5, 16, 16, 64).to(cuda).requires_grad_(True)
+    dy = randbf(gen, 5, 16, 16, 72).to(cuda)
+
+    def grads():
+        conv.weight.grad = None
+        conv(x).backward(dy)
+        return conv.weight.grad.clone()
+
+    whole = grads()
+    old, autograd.WGRAD_WINDOW_BYTES = autograd.WGRAD_WINDOW_BYTES, 2 * 576 * 2 * 256      # two images per group (K9 = 576, 256 pixels each)
+    try:
+        grouped = grads()
+    finally:
+        autograd.WGRAD_WINDOW_BYTES = old
+    ref = torch.nn.grad.conv2d_weight(x.detach().float().permute(0, 3, 1, 2), conv.weight.shape, dy.float().permute(0, 3, 1, 2), padding=1)
+    assert rel_l2(whole, ref) < 6e-3 and rel_l2(grouped, ref) < 6e-3
+    assert rel_l2(grouped, whole) < 6e-3 and not torch.equal(grouped, torch.zeros_like(grouped))
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(1000, 320, 200, None), (2048, 1280, 640, 1), (2048, 10240, 1280, None), (2048, 1280, 640, 3),
                                           (4104, 136, 72, None), (64, 128, 128, None), (8192, 2560, 640, None), (333, 1288, 24, 4)])
 def test_gemm_nn_untransposed_weight(cuda, gen, M, N, K, splits):
