@@ -384,6 +384,40 @@ def test_unet_sdxl_style_full_size(cuda):
     assert rel_l2(out, ref) < 1e-2
 
 
+def test_every_aspect_bucket_runs(small_unet, vae, cuda):
+    """evaluate() snaps an image to one of eleven ~1-megapixel aspect buckets (src/lbm/inference/inference.py:12-24,
+    45-50): every bucket's geometry goes through encode -> sample -> decode -- non-square latents, token counts from 960
+    to 16,384, and the tiled decode whenever a latent side exceeds 128 (ragged last tiles 16 to 112 wide) -- with the
+    result finite, of the bucket's size, and for the tiled cases equal to the restated reference tiling of untiled
+    decodes."""
+    from lbm_amd.inference.inference import ASPECT_RATIOS
+    from oracle import bridge_ref as br
+    m, _ = small_unet
+    w, _ = vae
+    model = _lbm(m, w)
+    g = torch.Generator().manual_seed(44)
+    seen_tiled = 0
+    for (width, height) in sorted(set(ASPECT_RATIOS.values())):
+        x = (torch.rand(1, 3, height, width, generator=g) * 2 - 1).to(BF).to(cuda)
+        eps = torch.randn(1, 4, height // 8, width // 8, generator=g).to(BF).to(cuda)
+        with torch.no_grad():
+            z = w.encode(x, eps=eps)
+            out = model.sample(z, num_steps=1)
+        assert z.shape == (1, 4, height // 8, width // 8)
+        assert out.shape == (1, 3, height, width) and bool(torch.isfinite(out.float()).all()), (width, height)
+        if max(height, width) // 8 > 128:
+            seen_tiled += 1
+            assert out.dtype == torch.float32
+            with torch.no_grad():
+                old_vae, model.vae = model.vae, None
+                lat = model.sample(z, num_steps=1)
+                model.vae = old_vae
+                ref = br.tiled_decode(lat.float().cpu(), lambda t: w.decode(t.to(BF).to(cuda)).float().cpu(),
+                                      tile=(128, 128), overlap=(16, 16), scale=8)
+            assert rel_l2(out, ref) < 2e-6, (width, height)
+    assert seen_tiled >= 8
+
+
 @pytest.mark.slow_oracle
 def test_unet_sd15_style_full_structure(cuda):
     """The relight denoiser with its full structure (src/lbm/inference/relight.py:61-120, 224-272: four levels
