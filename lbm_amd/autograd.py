@@ -299,16 +299,19 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, heads, dim_head, scale):
-        if q.shape[1] % 8:
-            raise NotImplementedError("training attention needs a query token count that is a multiple of 8")
         ctx.cfg = (heads, dim_head, scale)
         Nk = k.shape[1]
         ctx.nk = Nk
+        ctx.nq = q.shape[1]
+        if ctx.nq % 8:
+            # a 2x2 / 6x6 token grid (deepest level of a small training resolution): zero query rows up to a multiple
+            # of 8; their outputs are dropped and their output gradients are zero, so they reach no gradient
+            q = torch.nn.functional.pad(q, (0, 0, 0, -ctx.nq % 8))
         if Nk % 8:
             # a handful of context tokens (lighting parameters): zero rows up to a multiple of 8, masked out of the softmax
             k = torch.nn.functional.pad(k, (0, 0, 0, -Nk % 8))
             v = torch.nn.functional.pad(v, (0, 0, 0, -Nk % 8))
-        elif (ops.flash_attn_bwd_supported(dim_head, q.shape[1], Nk) and q.is_contiguous()
+        elif (ctx.nq == q.shape[1] and ops.flash_attn_bwd_supported(dim_head, q.shape[1], Nk) and q.is_contiguous()
                 and k.is_contiguous() and v.is_contiguous()):
             # fused backward available: keep the output and the row log-sum-exp instead of recomputing P
             o, lse = ops.flash_attn(q, k, ops.transpose(v), heads, dim_head, scale, return_lse=True)
@@ -325,7 +328,7 @@ class AttentionFn(torch.autograd.Function):
             o = torch.empty_like(q)
             ops.gemm_nt(p, ops.transpose(v).view(B, heads, dim_head, k.shape[1]), out=_heads(o, heads, dim_head))
         ctx.save_for_backward(q, k, v)
-        return o
+        return o if ctx.nq == q.shape[1] else o[:, :ctx.nq].contiguous()
 
     @staticmethod
     def _scores(q, k, H, D, scale, nk):
@@ -344,6 +347,8 @@ class AttentionFn(torch.autograd.Function):
         q, k, v = ctx.saved_tensors
         B, Nq, C = q.shape
         Nk = k.shape[1]
+        if ctx.nq < Nq:
+            do = torch.nn.functional.pad(do, (0, 0, 0, Nq - ctx.nq))
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         q4, k4, v4, do4 = (_heads(t, H, D) for t in (q, k, v, do))
         p = ops.softmax_rows(AttentionFn._scores(q, k, H, D, scale, ctx.nk))                 # [B, H, Nq, Nk] bf16
@@ -358,7 +363,7 @@ class AttentionFn(torch.autograd.Function):
         ops.gemm_nt(ds, kt4, out=_heads(dq, H, D))                                           # dQ = dS K
         dst = ops.transpose(ds.view(B * H, Nq, Nk)).view(B, H, Nk, Nq)
         ops.gemm_nt(dst, qt4, out=_heads(dk, H, D))                                          # dK = dS^T Q
-        return dq, dk[:, :ctx.nk], dv[:, :ctx.nk], None, None, None
+        return dq[:, :ctx.nq], dk[:, :ctx.nk], dv[:, :ctx.nk], None, None, None
 
 
 class SelfAttnQKVFn(torch.autograd.Function):

@@ -169,11 +169,13 @@ def test_silu_geglu_backward(cuda, gen):
     assert rel_l2(hg.grad, hr.grad) < 5e-3
 
 
-# token counts that are multiples of 64: fused flash backward; (2, 72, 40, ...): recomputed scores
+# token counts that are multiples of 64: fused flash backward; (2, 72, 40, ...): recomputed scores; query counts that are
+# not multiples of 8 (2x2 and 6x6 token grids of small training resolutions, with 5 lighting tokens as keys): zero-padded rows
 @pytest.mark.parametrize("B,N,Nk,H,D", [(2, 256, 256, 5, 64), (1, 1024, 1024, 2, 64), (2, 384, 128, 3, 64),
                                         (2, 192, 192, 2, 64), (2, 64, 64, 4, 40), (1, 320, 192, 3, 40),
                                         (2, 256, 256, 2, 80), (1, 64, 128, 3, 80), (2, 128, 64, 2, 160),
-                                        (1, 256, 256, 1, 160), (2, 72, 40, 2, 64)])
+                                        (1, 256, 256, 1, 160), (2, 72, 40, 2, 64), (2, 4, 4, 8, 160), (2, 36, 5, 2, 80),
+                                        (1, 60, 64, 2, 64), (1, 36, 36, 1, 512)])
 def test_attention_backward(cuda, gen, B, N, Nk, H, D):
     from lbm_amd.autograd import AttentionFn
     C = H * D

@@ -90,7 +90,7 @@ def test_training_entry_runs_the_shipped_fill_lighting_simple_config(cuda, tmp_p
     on an injected loader, a checkpoint per step, resumable by get_model-style loading (model.-prefixed keys)."""
     from lbm_amd.trainer import main
     g = torch.Generator().manual_seed(3)
-    R = 256            # latent 32x32: the mid-block attention sees 4x4 = 16 tokens (the training attention wants a multiple of 8)
+    R = 128            # latent 16x16: the mid-block attention sees 2x2 = 4 tokens (zero-padded query rows in training)
     batch = {"source": (torch.rand(2, 3, R, R, generator=g) * 2 - 1).to(torch.bfloat16),
              "target": (torch.rand(2, 3, R, R, generator=g) * 2 - 1).to(torch.bfloat16),
              "depth": torch.rand(2, 1, R, R, generator=g).to(torch.bfloat16),
