@@ -98,7 +98,7 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape
         dx = dw = db = dres = drv = None
         if ctx.needs_input_grad[0]:
-            if ops.gemm_nn_ok(dy2, weight):
+            if ops.gemm_nn_ok(dy2, weight) and ops.gemm_nn_wins(dy2.shape[0], N, K):
                 dx = ops.gemm_nn(dy2, weight)                   # reads the parameter as stored: no W^T copy per step
             else:
                 dx = _linear_maybe_splitk(dy2, ctx.mod.packed_t(), None)
@@ -401,7 +401,8 @@ class SelfAttnQKVFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             stack = ctx.mod._qkv_stack()[0]
             is_view = stack.data_ptr() in (mod_w.data_ptr() for mod_w in (ctx.mod.to_q.weight, ctx.mod.to_k.weight, ctx.mod.to_v.weight))
-            if is_view and ops.gemm_nn_ok(d2, stack):    # (a stack that had to be concatenated is no cheaper than W^T)
+            if is_view and ops.gemm_nn_ok(d2, stack) and ops.gemm_nn_wins(d2.shape[0], *stack.shape):
+                # (a stack that had to be concatenated is no cheaper than W^T)
                 dx = ops.gemm_nn(d2, stack).reshape(x.shape)
             else:
                 dx = ops.linear(d2, ctx.mod.packed_qkv_t())[:, :x.shape[-1]].reshape(x.shape)

@@ -1012,12 +1012,24 @@ def _pad_rows8(x: torch.Tensor) -> torch.Tensor:
 _GEMM_NN = os.environ.get("LBM_NO_GEMM_NN") is None      # LBM_NO_GEMM_NN=1: input gradients through W^T copies (A/B runs)
 
 
+_GEMM_NN_ALWAYS = os.environ.get("LBM_GEMM_NN_ALWAYS") is not None     # every eligible input gradient (A/B runs)
+
+
 def gemm_nn_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     """operands the untransposed-weight input-gradient kernel takes: bf16, unit column stride, 16-byte aligned rows"""
     return (_GEMM_NN and a.is_cuda and a.dtype == bf16 and w.dtype == bf16 and a.dim() == 2 and w.dim() == 2
             and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[0] and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
             and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
             and 129 * a.stride(0) * 2 < (1 << 31))
+
+
+def gemm_nn_wins(M: int, N: int, K: int) -> bool:
+    """True where the untransposed-weight kernel beats 'transpose W once per step, then the implicit-GEMM kernel' for
+    dX[M, K] = dY[M, N] . W[N, K].  Measured on MI355X (scripts/bench_gemm_nn.py): its 128x128 tile is bound by the
+    transposing LDS reads at about 500-750 TFLOP/s, the implicit-GEMM kernel reaches 800-1240 on the same product once
+    M >= 8192; at 2048 rows it is ahead only where the reduction is deep and the output narrow (N >= 3 K: it splits the
+    reduction across workgroups), 84 vs 127 us at N 10240 / K 1280, 43 vs 51 us at 3840 / 1280."""
+    return _GEMM_NN_ALWAYS or (M <= 4096 and N >= 3 * K)
 
 
 def gemm_nn(a: torch.Tensor, w: torch.Tensor, splits: Optional[int] = None) -> torch.Tensor:
