@@ -50,6 +50,7 @@ class IgemmDesc(C.Structure):
         ("in_f32", i32),
         ("out_up2", i32), ("gn_nslab", i32), ("gn_strip_off", i32),
         ("smx_mode", i32), ("smx_max", vp), ("smx_part", vp),
+        ("f32_chunks", i32), ("f32_part", vp),
     ]
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "lbmk_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
     "lbmk_igemm_tiles": (i32, [C.POINTER(i32), C.POINTER(i32), i32]),
     "lbmk_igemm_smx_parts": (i32, [i32]),
+    "lbmk_igemm_f32_chunks": (i32, [i32]),
+    "lbmk_igemm_f32_split_pays": (i32, [i32, i32, i32, i32]),
     "lbmk_igemm_gn_partial_floats": (i64, [i32, i32, i32, i32, i32, i32]),
     "lbmk_groupnorm_from_partials": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_groupnorm_scratch_floats": (i64, [i32, i32, i32, i32]),

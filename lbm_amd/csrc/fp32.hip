@@ -15,7 +15,28 @@ constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = 132;   // 132: rows 4 apart 
 // 256 threads = 4 waves, each a 64x64 corner of the 128x128 tile as 2x2 MFMA tiles of 32x32; 16-deep K tiles staged
 // through LDS k-major (the MFMA operand of lane l is element [k = l >> 5][row = l & 31]: one conflict-free
 // ds_read_b32 per operand), next tile's global loads issued before the current tile's products.
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const lbmk_igemm_desc d) {
+// K is summed in chunks of CHUNK_TILES K tiles (512 deep): products of a chunk run as one fmaf chain in the accumulators,
+// and the chunk sums are added in chunk order.  SPLIT: workgroup z of grid.z owns chunk z and writes its raw chunk sum to
+// d.f32_part[z][M][N]; splitk_finish_f32_kernel adds the chunks in the same order and applies the epilogue, so both forms
+// return the same bits.
+constexpr int CHUNK_TILES = 32;
+
+// alpha, bias, per-image row vector, residual, activation of one output element (one definition for both forms)
+__device__ __forceinline__ float f32_epilogue(const lbmk_igemm_desc& d, float sum, int m, int n, int ohw, const float* res) {
+  float x = fmaf(d.alpha, sum, (d.bias && !d.bias_per_m) ? d.bias[n] : 0.f);
+  if (d.bias && d.bias_per_m) x += d.bias[m];
+  if (d.rowvec) x += ((const float*)d.rowvec)[(int64_t)(m / ohw) * d.rowvec_ld + n];
+  if (res) x += res[(int64_t)m * d.ldr + n];
+  if (d.act == LBMK_ACT_SILU) x = x / (1.0f + expf(-x));
+  else if (d.act == LBMK_ACT_RELU) x = fmaxf(x, 0.f);
+  return x;
+}
+
+// CHUNKED (unsplit form, K > 512): a second accumulator set holds the sum of the finished chunks; 64 more registers, two
+// waves per SIMD instead of three (-3 % on the VAE's convolutions; capping the registers at three waves spills 31 of them
+// into the loop, -8 %).
+template <bool SPLIT, bool CHUNKED>
+__global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const lbmk_igemm_desc d) {
   __shared__ float As[BK][LDS_LD];
   __shared__ float Ws[BK][LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -24,7 +45,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const lbmk_igemm_desc d)
   const float* w = (const float*)d.w;
   float* out = (float*)d.out;
   const float* res = (const float*)d.residual;
-  {
+  if constexpr (!SPLIT) {
     const int z = blockIdx.z;
     if (d.batch_inner > 1) {
       const int64_t zo = z / d.batch_inner, zi = z % d.batch_inner;
@@ -97,13 +118,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const lbmk_igemm_desc d)
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = lane & 31, lk = lane >> 5;
-  const int nkt = (d.K + BK - 1) / BK;
-  fetch(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();            // every wave is done reading the previous tile
-    stage();
-    __syncthreads();
-    if (kt + 1 < nkt) fetch(kt + 1);
+  const int nkt_all = (d.K + BK - 1) / BK;
+  const int kt_begin = SPLIT ? (int)blockIdx.z * CHUNK_TILES : 0;
+  const int kt_end = SPLIT ? (kt_begin + CHUNK_TILES < nkt_all ? kt_begin + CHUNK_TILES : nkt_all) : nkt_all;
+  auto tile_products = [&]() {
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int k = kk * 2 + lk;
@@ -114,29 +132,85 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const lbmk_igemm_desc d)
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-  }
-  // epilogue: lane = output column, registers = rows (row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5))
-  const float* rowvec = (const float*)d.rowvec;
+  };
+  fetch(kt_begin);
+  if constexpr (SPLIT) {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      __syncthreads();            // every wave is done reading the previous tile
+      stage();
+      __syncthreads();
+      if (kt + 1 < kt_end) fetch(kt + 1);
+      tile_products();
+    }
+    // raw chunk sum: lane = output column, registers = rows (row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5))
+    float* part = d.f32_part + (int64_t)blockIdx.z * d.M * d.N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn + j * 32 + lr;
-      if (n >= d.N) continue;
-      const float bn = (d.bias && !d.bias_per_m) ? d.bias[n] : 0.f;
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + j * 32 + lr;
+        if (n >= d.N) continue;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lk;
-        if (m >= d.M) continue;
-        float x = d.alpha * acc[i][j][v] + bn;
-        if (d.bias && d.bias_per_m) x += d.bias[m];
-        if (rowvec) x += rowvec[(int64_t)(m / ohw) * d.rowvec_ld + n];
-        if (res) x += res[(int64_t)m * d.ldr + n];
-        if (d.act == LBMK_ACT_SILU) x = x / (1.0f + expf(-x));
-        else if (d.act == LBMK_ACT_RELU) x = fmaxf(x, 0.f);
-        out[(int64_t)m * d.ldo + n] = x;
+        for (int v = 0; v < 16; ++v) {
+          const int m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lk;
+          if (m < d.M) part[(int64_t)m * d.N + n] = acc[i][j][v];
+        }
+      }
+  } else {
+    // chunk sums are added in chunk order (same association as the split form's finishing pass)
+    f32x16 tot[2][2];
+    constexpr bool chunked = CHUNKED;   // one chunk (host: K <= 512): the accumulators are the result
+    if (chunked) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) tot[i][j][v] = 0.f;
+    }
+    for (int c0 = 0; c0 < nkt_all; c0 += CHUNK_TILES) {
+      const int c1 = c0 + CHUNK_TILES < nkt_all ? c0 + CHUNK_TILES : nkt_all;
+      for (int kt = c0; kt < c1; ++kt) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (kt + 1 < nkt_all) fetch(kt + 1);
+        tile_products();
+      }
+      if (chunked) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { tot[i][j][v] += acc[i][j][v]; acc[i][j][v] = 0.f; }
       }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn + j * 32 + lr;
+        if (n >= d.N) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int m = m0 + wm + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lk;
+          if (m >= d.M) continue;
+          out[(int64_t)m * d.ldo + n] = f32_epilogue(d, chunked ? tot[i][j][v] : acc[i][j][v], m, n, ohw, res);
+        }
+      }
+  }
+}
+
+// sum of the chunk partials in chunk order + epilogue; one thread per output element, consecutive threads along n
+__global__ __launch_bounds__(256) void splitk_finish_f32_kernel(const lbmk_igemm_desc d) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t MN = (int64_t)d.M * d.N;
+  if (idx >= MN) return;
+  const int m = (int)(idx / d.N), n = (int)(idx - (int64_t)m * d.N);
+  float s = 0.f;
+  for (int z = 0; z < d.f32_chunks; ++z) s += d.f32_part[z * MN + idx];
+  ((float*)d.out)[(int64_t)m * d.ldo + n] = f32_epilogue(d, s, m, n, d.OH * d.OW, (const float*)d.residual);
 }
 
 // ---- GroupNorm(+SiLU), f32: slab partial sums in f64 -> mean / rstd -> apply ------------------------------
@@ -378,8 +452,32 @@ int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream) {
   LBMK_REQUIRE(d->batch_inner <= 1 || (!d->residual && d->batch % d->batch_inner == 0), "igemm (f32): batch_inner");
   dim3 grid((d->M + BM - 1) / BM, (d->N + BN - 1) / BN, d->batch);
   LBMK_REQUIRE(grid.y <= 65535, "igemm (f32): N=%d too large for one launch", d->N);
-  hipLaunchKernelGGL(igemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
+  if (d->f32_chunks > 1) {
+    LBMK_REQUIRE(d->batch == 1 && d->batch_inner <= 1 && d->f32_part && lbmk_aligned(d->f32_part, 4) &&
+                     d->f32_chunks == lbmk_igemm_f32_chunks(d->K),
+                 "igemm (f32): a split launch takes batch 1, a partial buffer and f32_chunks = %d (got %d)",
+                 lbmk_igemm_f32_chunks(d->K), d->f32_chunks);
+    grid.z = d->f32_chunks;
+    hipLaunchKernelGGL((igemm_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *d);
+    if (int rc = lbmk_check_launch("igemm (f32, chunks)")) return rc;
+    const int64_t MN = (int64_t)d->M * d->N;
+    hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    return lbmk_check_launch("igemm (f32, finish)");
+  }
+  if (lbmk_igemm_f32_chunks(d->K) > 1) hipLaunchKernelGGL((igemm_f32_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL((igemm_f32_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, *d);
   return lbmk_check_launch("igemm (f32)");
+}
+
+extern "C" int lbmk_igemm_f32_chunks(int K) { return (K + BK * CHUNK_TILES - 1) / (BK * CHUNK_TILES); }
+
+// few output tiles against many chunks: the chunked launch fills the chip, and its partial traffic (2 x chunks x M x N x 4
+// bytes) is small beside the products
+extern "C" int lbmk_igemm_f32_split_pays(int M, int N, int K, int batch) {
+  if (batch != 1 || M <= 0 || N <= 0) return 0;
+  const int chunks = lbmk_igemm_f32_chunks(K);
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  return chunks >= 2 && tiles <= lbmk_num_cus() ? 1 : 0;
 }
 
 extern "C" int64_t lbmk_groupnorm_f32_scratch_floats(int B, int G) { return (int64_t)B * G * (GN_SLABS * 4 + 2); }

@@ -42,6 +42,44 @@ def test_conv2d_f32(ops, cuda, cin, cout, k, stride, up2, H):
     assert rel_l2(y, full) < 2e-6
 
 
+@pytest.mark.parametrize("case", ["linear_deep", "conv_deep", "linear_two_chunks"])
+def test_f32_k_chunks_split_or_not_same_bits(ops, cuda, case):
+    """few-row, deep-K layers run as one workgroup per (tile, 512-deep K chunk) plus a finishing pass; the single launch adds
+    its own chunk sums in the same order, so both return the same bits (and both match f64 to f32 rounding)"""
+    g = torch.Generator().manual_seed(11)
+    if case == "conv_deep":
+        x = torch.randn(1, 16, 16, 320, generator=g)
+        w = torch.randn(200, 320, 3, 3, generator=g) * (9 * 320) ** -0.5
+        b = torch.randn(200, generator=g)
+        pw = ops.pack_conv_weight(w.to(cuda), b.to(cuda))
+        rv, res = torch.randn(1, pw.N, generator=g), torch.randn(1, 16, 16, pw.N, generator=g)
+        run = lambda: ops.conv2d(x.to(cuda), pw, stride=1, pad=(1, 1), rowvec=rv.to(cuda), residual=res.to(cuda), act=ops.ACT_SILU)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        full = torch.zeros_like(res, dtype=torch.float64)
+        full[..., :200] = ref
+        full = F.silu(full + rv[:, None, None, :].double() + res.double())[..., :200]
+        cut = lambda y: y[..., :200]
+    else:
+        M, N, K = (200, 264, 2568) if case == "linear_deep" else (384, 640, 640)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * K ** -0.5
+        b = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        pw = ops.pack_linear_weight(w.to(cuda), b.to(cuda))
+        run = lambda: ops.linear(x.to(cuda), pw, residual=res.to(cuda))
+        full = x.double() @ w.double().t() + b.double() + res.double()
+        cut = lambda y: y
+    assert ops.lib.lbmk_igemm_f32_split_pays(*( (256, 200, 2880, 1) if case == "conv_deep" else (M, N, K, 1) )) == 1
+    split = run()
+    saved, ops._F32_SPLIT = ops._F32_SPLIT, False
+    try:
+        single = run()
+    finally:
+        ops._F32_SPLIT = saved
+    assert torch.equal(split, single)
+    assert rel_l2(cut(split), full) < 2e-6
+
+
 def test_linear_geglu_gemm_f32(ops, cuda):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(3, 50, 72, generator=g)
