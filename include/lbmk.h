@@ -106,17 +106,17 @@ typedef struct lbmk_igemm_desc {
   const float* smx_max; /* pass 2: f32 [batch][M] row maxima (same alpha as pass 1)                               */
   float* smx_part;      /* f32 [batch][M][lbmk_igemm_smx_parts(N)]                                                */
   int32_t f32_chunks;   /* fp32 mode only.  0 / 1: one workgroup walks the whole K range of its tile.  > 1 (must equal    */
-  float* f32_part;      /* lbmk_igemm_f32_chunks(K); batch 1): the 512-deep chunks of K run as separate workgroups that
+  float* f32_part;      /* lbmk_igemm_f32_chunks(K); batch 1): the chunks of K (128 deep, doubled until there are at most 32) run as separate workgroups that
                            write raw products to f32_part[chunk][M][N] (f32_chunks * M * N floats), and a finishing pass
                            adds them in chunk order and applies alpha / bias / rowvec / residual / activation.  The
-                           single-workgroup kernel adds its own 512-deep chunk sums in the same order, so a layer
+                           single-workgroup kernel adds its own chunk sums in the same order, so a layer
                            returns the same bits either way (the choice may depend on the batch size, the result
                            does not).  For the few-row, deep-K layers of a small batch (256 ... 1024 tokens against
                            K up to 23,040: 20 ... 80 tiles on 256 CUs)                                            */
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
-/* fp32 mode: number of 512-deep K chunks of a layer (the f32_chunks a split launch must carry), and whether splitting
+/* fp32 mode: number of K chunks of a layer (the f32_chunks a split launch must carry), and whether splitting
  * pays for this shape (few output tiles, several chunks): 0 = launch unsplit */
 int lbmk_igemm_f32_chunks(int K);
 int lbmk_igemm_f32_split_pays(int M, int N, int K, int batch);

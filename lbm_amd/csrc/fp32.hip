@@ -5,6 +5,7 @@
 // library expf / sinf / cosf / erff instead of the hardware approximations.  Attention runs unfused on these
 // pieces (scores GEMM -> row softmax -> PV GEMM).  Peak of the f32 matrix path is 157 TFLOP/s, 1/16 of bf16.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -15,11 +16,19 @@ constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = 132;   // 132: rows 4 apart 
 // 256 threads = 4 waves, each a 64x64 corner of the 128x128 tile as 2x2 MFMA tiles of 32x32; 16-deep K tiles staged
 // through LDS k-major (the MFMA operand of lane l is element [k = l >> 5][row = l & 31]: one conflict-free
 // ds_read_b32 per operand), next tile's global loads issued before the current tile's products.
-// K is summed in chunks of CHUNK_TILES K tiles (512 deep): products of a chunk run as one fmaf chain in the accumulators,
-// and the chunk sums are added in chunk order.  SPLIT: workgroup z of grid.z owns chunk z and writes its raw chunk sum to
+// K is summed in chunks of chunk_tiles(K) K tiles: products of a chunk run as one fmaf chain in the accumulators, and the
+// chunk sums are added in chunk order.  SPLIT: workgroup z of grid.z owns chunk z and writes its raw chunk sum to
 // d.f32_part[z][M][N]; splitk_finish_f32_kernel adds the chunks in the same order and applies the epilogue, so both forms
-// return the same bits.
-constexpr int CHUNK_TILES = 32;
+// return the same bits.  The chunk depth is a function of the layer's K alone, never of the row count: 128 deep, doubled
+// until there are at most 32 chunks -- a 256-token, 1280-wide, 1280-deep layer is 2 x 10 tiles x 10 chunks = 200
+// workgroups for 256 CUs.  (Fewer, deeper chunks for wide layers -- at most 160 / column tiles -- measured slower over the
+// 512x512 batch-1 step: 90.5 against 87.5 ms.)
+__host__ __device__ inline int chunk_tiles(int K) {
+  const int nkt = (K + BK - 1) / BK;
+  int ct = 8;
+  while ((nkt + ct - 1) / ct > 32) ct *= 2;
+  return ct;
+}
 
 // alpha, bias, per-image row vector, residual, activation of one output element (one definition for both forms)
 __device__ __forceinline__ float f32_epilogue(const lbmk_igemm_desc& d, float sum, int m, int n, int ohw, const float* res) {
@@ -32,7 +41,7 @@ __device__ __forceinline__ float f32_epilogue(const lbmk_igemm_desc& d, float su
   return x;
 }
 
-// CHUNKED (unsplit form, K > 512): a second accumulator set holds the sum of the finished chunks; 64 more registers, two
+// CHUNKED (unsplit form, more than one chunk): a second accumulator set holds the sum of the finished chunks; 64 more registers, two
 // waves per SIMD instead of three (-3 % on the VAE's convolutions; capping the registers at three waves spills 31 of them
 // into the loop, -8 %).
 template <bool SPLIT, bool CHUNKED>
@@ -119,20 +128,29 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = lane & 31, lk = lane >> 5;
   const int nkt_all = (d.K + BK - 1) / BK;
+  const int CHUNK_TILES = chunk_tiles(d.K);
   const int kt_begin = SPLIT ? (int)blockIdx.z * CHUNK_TILES : 0;
   const int kt_end = SPLIT ? (kt_begin + CHUNK_TILES < nkt_all ? kt_begin + CHUNK_TILES : nkt_all) : nkt_all;
-  auto tile_products = [&]() {
+  // `first`: the first K tile of a chunk starts its accumulators from the constant zero (the matrix instruction takes an
+  // inline 0 as its addend), so nothing is cleared between chunks
+  auto tile_products = [&](auto first) {
+    f32x16 zero;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) zero[v] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int k = kk * 2 + lk;
       const float a0 = As[k][wm + lr], a1 = As[k][wm + 32 + lr];
       const float b0 = Ws[k][wn + lr], b1 = Ws[k][wn + 32 + lr];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const bool z = decltype(first)::value && kk == 0;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, z ? zero : acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, z ? zero : acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, z ? zero : acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, z ? zero : acc[1][1], 0, 0, 0);
     }
   };
+  const std::true_type FIRST{};
+  const std::false_type REST{};
   fetch(kt_begin);
   if constexpr (SPLIT) {
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -140,7 +158,8 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
       stage();
       __syncthreads();
       if (kt + 1 < kt_end) fetch(kt + 1);
-      tile_products();
+      if (kt == kt_begin) tile_products(FIRST);
+      else tile_products(REST);
     }
     // raw chunk sum: lane = output column, registers = rows (row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5))
     float* part = d.f32_part + (int64_t)blockIdx.z * d.M * d.N;
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
   } else {
     // chunk sums are added in chunk order (same association as the split form's finishing pass)
     f32x16 tot[2][2];
-    constexpr bool chunked = CHUNKED;   // one chunk (host: K <= 512): the accumulators are the result
+    constexpr bool chunked = CHUNKED;   // one chunk (host: K <= 128): the accumulators are the result
     if (chunked) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -175,7 +194,8 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
         stage();
         __syncthreads();
         if (kt + 1 < nkt_all) fetch(kt + 1);
-        tile_products();
+        if (kt == c0) tile_products(FIRST);
+        else tile_products(REST);
       }
       if (chunked) {
 #pragma unroll
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) { tot[i][j][v] += acc[i][j][v]; acc[i][j][v] = 0.f; }
+            for (int v = 0; v < 16; ++v) tot[i][j][v] += acc[i][j][v];
       }
     }
 #pragma unroll
@@ -469,7 +489,10 @@ int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream) {
   return lbmk_check_launch("igemm (f32)");
 }
 
-extern "C" int lbmk_igemm_f32_chunks(int K) { return (K + BK * CHUNK_TILES - 1) / (BK * CHUNK_TILES); }
+extern "C" int lbmk_igemm_f32_chunks(int K) {
+  const int ct = chunk_tiles(K), nkt = (K + BK - 1) / BK;
+  return (nkt + ct - 1) / ct;
+}
 
 // few output tiles against many chunks: the chunked launch fills the chip, and its partial traffic (2 x chunks x M x N x 4
 // bytes) is small beside the products
