@@ -224,15 +224,38 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
   }
 }
 
-// sum of the chunk partials in chunk order + epilogue; one thread per output element, consecutive threads along n
+// sum of the chunk partials in chunk order + epilogue; VEC consecutive output columns per thread (VEC = 4: N % 4 == 0, so
+// every 16-byte partial load is aligned), the chunk loop unrolled four deep so that four loads are in flight per thread
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_finish_f32_kernel(const lbmk_igemm_desc d) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
   const int64_t MN = (int64_t)d.M * d.N;
   if (idx >= MN) return;
   const int m = (int)(idx / d.N), n = (int)(idx - (int64_t)m * d.N);
-  float s = 0.f;
-  for (int z = 0; z < d.f32_chunks; ++z) s += d.f32_part[z * MN + idx];
-  ((float*)d.out)[(int64_t)m * d.ldo + n] = f32_epilogue(d, s, m, n, d.OH * d.OW, (const float*)d.residual);
+  typedef __attribute__((ext_vector_type(VEC))) float vec_t;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  const float* p = d.f32_part + idx;
+  int z = 0;
+  for (; z + 4 <= d.f32_chunks; z += 4) {
+    vec_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const vec_t*)(p + (z + u) * MN);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += v[u][e];
+  }
+  for (; z < d.f32_chunks; ++z) {
+    const vec_t v = *(const vec_t*)(p + z * MN);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] += v[e];
+  }
+  const int ohw = d.OH * d.OW;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e)
+    ((float*)d.out)[(int64_t)m * d.ldo + n + e] = f32_epilogue(d, s[e], m, n + e, ohw, (const float*)d.residual);
 }
 
 // ---- GroupNorm(+SiLU), f32: slab partial sums in f64 -> mean / rstd -> apply ------------------------------
@@ -483,7 +506,10 @@ int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream) {
     hipLaunchKernelGGL((igemm_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *d);
     if (int rc = lbmk_check_launch("igemm (f32, chunks)")) return rc;
     const int64_t MN = (int64_t)d->M * d->N;
-    hipLaunchKernelGGL(splitk_finish_f32_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    if (d->N % 4 == 0 && lbmk_aligned(d->f32_part, 16))
+      hipLaunchKernelGGL(splitk_finish_f32_kernel<4>, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    else
+      hipLaunchKernelGGL(splitk_finish_f32_kernel<1>, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
     return lbmk_check_launch("igemm (f32, finish)");
   }
   if (lbmk_igemm_f32_chunks(d->K) > 1) hipLaunchKernelGGL((igemm_f32_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, *d);
