@@ -116,8 +116,9 @@ typedef struct lbmk_igemm_desc {
 } lbmk_igemm_desc;
 
 int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
-/* fp32 mode: number of K chunks of a layer (the f32_chunks a split launch must carry), and whether splitting
- * pays for this shape (few output tiles, several chunks): 0 = launch unsplit */
+/* fp32 mode (the reference's torch_dtype=torch.float32 configuration, src/lbm/inference/utils.py:21-26, 81-82, whose
+ * layers are torch's f32 convolutions / linears): number of K chunks of a layer (the f32_chunks a split launch must
+ * carry), and whether splitting pays for this shape (few output tiles, several chunks): 0 = launch unsplit */
 int lbmk_igemm_f32_chunks(int K);
 int lbmk_igemm_f32_split_pays(int M, int N, int K, int batch);
 int lbmk_igemm_smx_parts(int N);
