@@ -172,3 +172,19 @@ def test_upsampling_convolution_is_four_parity_convolutions():
         got = F.conv2d(xp, w2.double())
         assert got.shape == (2, 4, 5, 7)
         assert torch.allclose(got, ref[:, :, py::2, px::2], atol=1e-5, rtol=1e-5), q
+
+
+def test_fp32_k_chunk_rule():
+    """fp32 mode sums K in chunks of 128, doubled until a layer has at most 32 of them; the count is a function of K alone
+    (so the split / unsplit choice, which looks at the row count, cannot change a result).  Host code of the library: no GPU."""
+    from lbm_amd._C import lib
+    want = {64: 1, 128: 1, 129: 2, 640: 5, 1280: 10, 2880: 23, 4096: 32, 4097: 17, 5120: 20, 11520: 23, 23040: 23}
+    for k, n in want.items():
+        assert lib.lbmk_igemm_f32_chunks(k) == n, (k, lib.lbmk_igemm_f32_chunks(k), n)
+    # the same rule restated: depth 128 * 2^j with the smallest j that leaves <= 32 chunks
+    for k in range(16, 30000, 331):
+        tiles = -(-k // 16)
+        ct = 8
+        while -(-tiles // ct) > 32:
+            ct *= 2
+        assert lib.lbmk_igemm_f32_chunks(k) == -(-tiles // ct)
