@@ -106,7 +106,7 @@ typedef struct lbmk_igemm_desc {
   const float* smx_max; /* pass 2: f32 [batch][M] row maxima (same alpha as pass 1)                               */
   float* smx_part;      /* f32 [batch][M][lbmk_igemm_smx_parts(N)]                                                */
   int32_t f32_chunks;   /* fp32 mode only.  0 / 1: one workgroup walks the whole K range of its tile.  > 1 (must equal    */
-  float* f32_part;      /* lbmk_igemm_f32_chunks(K); batch 1): the chunks of K (128 deep, doubled until there are at most 32) run as separate workgroups that
+  float* f32_part;      /* lbmk_igemm_f32_chunks(K, N, OH * OW); batch 1): the chunks of K (a function of the layer, not of the row count) run as separate workgroups that
                            write raw products to f32_part[chunk][M][N] (f32_chunks * M * N floats), and a finishing pass
                            adds them in chunk order and applies alpha / bias / rowvec / residual / activation.  The
                            single-workgroup kernel adds its own chunk sums in the same order, so a layer
@@ -119,8 +119,8 @@ int lbmk_igemm(const lbmk_igemm_desc* d, void* stream);
 /* fp32 mode (the reference's torch_dtype=torch.float32 configuration, src/lbm/inference/utils.py:21-26, 81-82, whose
  * layers are torch's f32 convolutions / linears): number of K chunks of a layer (the f32_chunks a split launch must
  * carry), and whether splitting pays for this shape (few output tiles, several chunks): 0 = launch unsplit */
-int lbmk_igemm_f32_chunks(int K);
-int lbmk_igemm_f32_split_pays(int M, int N, int K, int batch);
+int lbmk_igemm_f32_chunks(int K, int N, int pixels_per_image /* OH * OW of the descriptor */);
+int lbmk_igemm_f32_split_pays(int M, int N, int K, int pixels_per_image, int batch);
 int lbmk_igemm_smx_parts(int N);
 /* floats behind gn_partial for a descriptor's shape, or -1 when the shape cannot carry fused statistics */
 int64_t lbmk_igemm_gn_partial_floats(int M, int N, int Cin, int OH, int OW, int gn_groups);

@@ -61,8 +61,8 @@ SIGNATURES = {
     "lbmk_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
     "lbmk_igemm_tiles": (i32, [C.POINTER(i32), C.POINTER(i32), i32]),
     "lbmk_igemm_smx_parts": (i32, [i32]),
-    "lbmk_igemm_f32_chunks": (i32, [i32]),
-    "lbmk_igemm_f32_split_pays": (i32, [i32, i32, i32, i32]),
+    "lbmk_igemm_f32_chunks": (i32, [i32, i32, i32]),
+    "lbmk_igemm_f32_split_pays": (i32, [i32, i32, i32, i32, i32]),
     "lbmk_igemm_gn_partial_floats": (i64, [i32, i32, i32, i32, i32, i32]),
     "lbmk_groupnorm_from_partials": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp]),
     "lbmk_groupnorm_scratch_floats": (i64, [i32, i32, i32, i32]),

@@ -21,14 +21,19 @@ constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = 132;   // 132: rows 4 apart 
 // K is summed in chunks of chunk_tiles(K) K tiles: products of a chunk run as one fmaf chain in the accumulators, and the
 // chunk sums are added in chunk order.  SPLIT: workgroup z of grid.z owns chunk z and writes its raw chunk sum to
 // d.f32_part[z][M][N]; splitk_finish_f32_kernel adds the chunks in the same order and applies the epilogue, so both forms
-// return the same bits.  The chunk depth is a function of the layer's K alone, never of the row count: 128 deep, doubled
-// until there are at most 32 chunks -- a 256-token, 1280-wide, 1280-deep layer is 2 x 10 tiles x 10 chunks = 200
-// workgroups for 256 CUs.  (Fewer, deeper chunks for wide layers -- at most 160 / column tiles -- measured slower over the
-// 512x512 batch-1 step: 90.5 against 87.5 ms.)
-__host__ __device__ inline int chunk_tiles(int K) {
+// return the same bits.  The chunk depth is a function of the LAYER -- K, N and the pixels per image (1 for a linear
+// layer) -- never of the row count: 128 deep, doubled until there are at most clamp(1024 / output tiles of one image, 1, 32)
+// chunks.  A 256-token, 1280-wide, 1280-deep layer is 2 x 10 tiles x 10 chunks = 200 workgroups for 256 CUs; a 64x64
+// convolution (96 tiles per image) gets 6 chunks instead of 23 (a quarter of the partial-sum traffic; a CU holds four
+// workgroups, so 1024 fill the chip); the VAE's
+// megapixel convolutions get one (no second accumulator set: three waves per SIMD instead of two).
+__host__ __device__ inline int chunk_tiles(int K, int N, int ohw) {
   const int nkt = (K + BK - 1) / BK;
+  const long tiles_img = (long)((ohw + BM - 1) / BM) * ((N + BN - 1) / BN);
+  long most = 1024 / tiles_img;
+  most = most > 32 ? 32 : most < 1 ? 1 : most;
   int ct = 8;
-  while ((nkt + ct - 1) / ct > 32) ct *= 2;
+  while ((nkt + ct - 1) / ct > most) ct *= 2;
   return ct;
 }
 
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int lr = lane & 31, lk = lane >> 5;
   const int nkt_all = (d.K + BK - 1) / BK;
-  const int CHUNK_TILES = chunk_tiles(d.K);
+  const int CHUNK_TILES = chunk_tiles(d.K, d.N, d.OH * d.OW);
   const int kt_begin = SPLIT ? (int)blockIdx.z * CHUNK_TILES : 0;
   const int kt_end = SPLIT ? (kt_begin + CHUNK_TILES < nkt_all ? kt_begin + CHUNK_TILES : nkt_all) : nkt_all;
   // `first`: the first K tile of a chunk starts its accumulators from the constant zero (the matrix instruction takes an
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, CHUNKED ? 2 : 3) void igemm_f32_kernel(const l
   } else {
     // chunk sums are added in chunk order (same association as the split form's finishing pass)
     f32x16 tot[2][2];
-    constexpr bool chunked = CHUNKED;   // one chunk (host: K <= 128): the accumulators are the result
+    constexpr bool chunked = CHUNKED;   // one chunk (host's choice): the accumulators are the result
     if (chunked) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -499,9 +504,9 @@ int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream) {
   LBMK_REQUIRE(grid.y <= 65535, "igemm (f32): N=%d too large for one launch", d->N);
   if (d->f32_chunks > 1) {
     LBMK_REQUIRE(d->batch == 1 && d->batch_inner <= 1 && d->f32_part && lbmk_aligned(d->f32_part, 4) &&
-                     d->f32_chunks == lbmk_igemm_f32_chunks(d->K),
+                     d->f32_chunks == lbmk_igemm_f32_chunks(d->K, d->N, d->OH * d->OW),
                  "igemm (f32): a split launch takes batch 1, a partial buffer and f32_chunks = %d (got %d)",
-                 lbmk_igemm_f32_chunks(d->K), d->f32_chunks);
+                 lbmk_igemm_f32_chunks(d->K, d->N, d->OH * d->OW), d->f32_chunks);
     grid.z = d->f32_chunks;
     hipLaunchKernelGGL((igemm_f32_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *d);
     if (int rc = lbmk_check_launch("igemm (f32, chunks)")) return rc;
@@ -512,21 +517,21 @@ int lbmk_igemm_f32_launch(const lbmk_igemm_desc* d, void* stream) {
       hipLaunchKernelGGL(splitk_finish_f32_kernel<1>, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
     return lbmk_check_launch("igemm (f32, finish)");
   }
-  if (lbmk_igemm_f32_chunks(d->K) > 1) hipLaunchKernelGGL((igemm_f32_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, *d);
+  if (lbmk_igemm_f32_chunks(d->K, d->N, d->OH * d->OW) > 1) hipLaunchKernelGGL((igemm_f32_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL((igemm_f32_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, *d);
   return lbmk_check_launch("igemm (f32)");
 }
 
-extern "C" int lbmk_igemm_f32_chunks(int K) {
-  const int ct = chunk_tiles(K), nkt = (K + BK - 1) / BK;
+extern "C" int lbmk_igemm_f32_chunks(int K, int N, int pixels_per_image) {
+  const int ct = chunk_tiles(K, N, pixels_per_image), nkt = (K + BK - 1) / BK;
   return (nkt + ct - 1) / ct;
 }
 
 // few output tiles against many chunks: the chunked launch fills the chip, and its partial traffic (2 x chunks x M x N x 4
 // bytes) is small beside the products
-extern "C" int lbmk_igemm_f32_split_pays(int M, int N, int K, int batch) {
+extern "C" int lbmk_igemm_f32_split_pays(int M, int N, int K, int pixels_per_image, int batch) {
   if (batch != 1 || M <= 0 || N <= 0) return 0;
-  const int chunks = lbmk_igemm_f32_chunks(K);
+  const int chunks = lbmk_igemm_f32_chunks(K, N, pixels_per_image);
   const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   return chunks >= 2 && tiles <= lbmk_num_cus() ? 1 : 0;
 }

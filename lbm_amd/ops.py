@@ -302,10 +302,10 @@ def _igemm(desc: IgemmDesc, alg_flops: Optional[float] = None, executed: Optiona
     """alg_flops: products of the reference operation this launch stands for (un-padded shapes; an upsampling
     convolution counts its 9 taps); executed: products the launch multiplies, when an algebraic shortcut makes that less"""
     part = None
-    if desc.in_f32 and _F32_SPLIT and lib.lbmk_igemm_f32_split_pays(desc.M, desc.N, desc.K, max(desc.batch, 1)):
+    if desc.in_f32 and _F32_SPLIT and lib.lbmk_igemm_f32_split_pays(desc.M, desc.N, desc.K, desc.OH * desc.OW, max(desc.batch, 1)):
         # fp32 mode, few output tiles and a deep K: one workgroup per (tile, K chunk) and a finishing pass;
         # same bits as the single launch (the library adds the chunk sums in the same order either way)
-        desc.f32_chunks = lib.lbmk_igemm_f32_chunks(desc.K)
+        desc.f32_chunks = lib.lbmk_igemm_f32_chunks(desc.K, desc.N, desc.OH * desc.OW)
         part = torch.empty(desc.f32_chunks * desc.M * desc.N, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
         desc.f32_part = part.data_ptr()
     if _profile is None:

@@ -69,7 +69,7 @@ def test_f32_k_chunks_split_or_not_same_bits(ops, cuda, case):
         run = lambda: ops.linear(x.to(cuda), pw, residual=res.to(cuda))
         full = x.double() @ w.double().t() + b.double() + res.double()
         cut = lambda y: y
-    assert ops.lib.lbmk_igemm_f32_split_pays(*( (256, 200, 2880, 1) if case == "conv_deep" else (M, N, K, 1) )) == 1
+    assert ops.lib.lbmk_igemm_f32_split_pays(*((256, 200, 2880, 256, 1) if case == "conv_deep" else (M, N, K, 1, 1))) == 1
     split = run()
     saved, ops._F32_SPLIT = ops._F32_SPLIT, False
     try:

@@ -175,16 +175,21 @@ def test_upsampling_convolution_is_four_parity_convolutions():
 
 
 def test_fp32_k_chunk_rule():
-    """fp32 mode sums K in chunks of 128, doubled until a layer has at most 32 of them; the count is a function of K alone
-    (so the split / unsplit choice, which looks at the row count, cannot change a result).  Host code of the library: no GPU."""
+    """fp32 mode sums K in chunks of 128, doubled until a layer has at most clamp(1024 / output tiles of one image, 1, 32)
+    of them; the count is a function of the layer (K, N, pixels per image), never of the row count (so the split /
+    unsplit choice, which looks at the row count, cannot change a result).  Host code of the library: no GPU."""
     from lbm_amd._C import lib
-    want = {64: 1, 128: 1, 129: 2, 640: 5, 1280: 10, 2880: 23, 4096: 32, 4097: 17, 5120: 20, 11520: 23, 23040: 23}
-    for k, n in want.items():
-        assert lib.lbmk_igemm_f32_chunks(k) == n, (k, lib.lbmk_igemm_f32_chunks(k), n)
-    # the same rule restated: depth 128 * 2^j with the smallest j that leaves <= 32 chunks
-    for k in range(16, 30000, 331):
-        tiles = -(-k // 16)
-        ct = 8
-        while -(-tiles // ct) > 32:
-            ct *= 2
-        assert lib.lbmk_igemm_f32_chunks(k) == -(-tiles // ct)
+    # (K, N, pixels per image) -> chunks; linear layers have one "pixel" per image
+    want = {(64, 1280, 1): 1, (128, 1280, 1): 1, (129, 1280, 1): 2, (1280, 1280, 1): 10, (5120, 1280, 1): 20,
+            (1280, 10240, 1): 10, (11520, 1280, 256): 23, (2880, 320, 4096): 6, (5760, 640, 1024): 23,
+            (1152, 128, 512 * 512): 1, (4608, 512, 128 * 128): 2, (2304, 256, 256 * 256): 1}
+    for (k, n, px), c in want.items():
+        assert lib.lbmk_igemm_f32_chunks(k, n, px) == c, (k, n, px, lib.lbmk_igemm_f32_chunks(k, n, px), c)
+    for k in range(16, 30000, 997):
+        for n, px in ((1280, 1), (320, 4096), (128, 1 << 20), (10240, 1)):
+            tiles = -(-k // 16)
+            most = max(1, min(32, 1024 // (-(-px // 128) * -(-n // 128))))
+            ct = 8
+            while -(-tiles // ct) > most:
+                ct *= 2
+            assert lib.lbmk_igemm_f32_chunks(k, n, px) == -(-tiles // ct)
