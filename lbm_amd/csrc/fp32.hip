@@ -361,6 +361,48 @@ __global__ __launch_bounds__(256) void ln32_kernel(const float* __restrict__ x, 
   }
 }
 
+// same, 16-byte accesses (C % 4 == 0, 16-byte aligned rows): a quarter of the memory instructions per row
+__global__ __launch_bounds__(256) void ln32_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
+  const int c4n = C >> 2;
+  f32x4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < c4n ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (lane + 64 * i < c4n) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dlt = v[i][e] - mean; q += dlt * dlt; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  f32x4* yr = (f32x4*)(y + (int64_t)row * C);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    if (c < c4n) {
+      const f32x4 g4 = gamma ? ((const f32x4*)gamma)[c] : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 b4 = beta ? ((const f32x4*)beta)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+      yr[c] = o;
+    }
+  }
+}
+
 // ---- row softmax f32 -> f32: one workgroup per row, three passes over the row --------------------------------
 __global__ __launch_bounds__(256) void softmax32_kernel(const float* __restrict__ s, float* __restrict__ p, int cols,
                                                         int64_t ld_in, int64_t ld_out) {
@@ -558,8 +600,12 @@ extern "C" int lbmk_groupnorm_f32(const void* x, void* y, const float* gamma, co
 extern "C" int lbmk_layernorm_f32(const void* x, void* y, const float* gamma, const float* beta, int rows, int C, float eps,
                                   void* stream) {
   LBMK_REQUIRE(x && y && rows > 0 && C > 0 && C <= 2048, "layernorm_f32: rows=%d C=%d (<= 2048)", rows, C);
-  hipLaunchKernelGGL(ln32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, gamma,
-                     beta, rows, C, eps);
+  if (C % 4 == 0 && lbmk_aligned(x, 16) && lbmk_aligned(y, 16) && (!gamma || lbmk_aligned(gamma, 16)) && (!beta || lbmk_aligned(beta, 16)))
+    hipLaunchKernelGGL(ln32_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, gamma,
+                       beta, rows, C, eps);
+  else
+    hipLaunchKernelGGL(ln32_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, gamma,
+                       beta, rows, C, eps);
   return lbmk_check_launch("layernorm_f32");
 }
 

@@ -104,6 +104,11 @@ def test_norms_softmax_f32(ops, cuda):
     assert rel_l2(y, ref) < 2e-6
     y = ops.layernorm(x.to(cuda), ga.to(cuda), be.to(cuda), 1e-5)
     assert rel_l2(y, F.layer_norm(x.double(), (320,), ga.double(), be.double(), 1e-5)) < 2e-6
+    for C in (1280, 2048, 322):     # 16-byte accesses when C % 4 == 0, element-wise otherwise
+        xc = torch.randn(37, C, generator=g) * 2 - 0.5
+        gc, bc = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        y = ops.layernorm(xc.to(cuda), gc.to(cuda), bc.to(cuda), 1e-5)
+        assert rel_l2(y, F.layer_norm(xc.double(), (C,), gc.double(), bc.double(), 1e-5)) < 2e-6
     s = torch.randn(7, 300, generator=g) * 4
     p = ops.softmax_rows(s.to(cuda).clone(), out_dtype=F32)
     assert rel_l2(p, torch.softmax(s.double(), -1)) < 2e-6
