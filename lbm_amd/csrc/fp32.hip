@@ -275,13 +275,30 @@ __global__ __launch_bounds__(256) void gn32_stats_kernel(const float* __restrict
   const int r0 = slab * rows, r1 = min(r0 + rows, HW);
   const float* base = x + (int64_t)b * HW * C + g * cpg;
   double s = 0.0, ss = 0.0;
-  const int64_t n = (int64_t)max(r1 - r0, 0) * cpg;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t row = r0 + i / cpg;
-    const int c = (int)(i % cpg);
-    const double v = (double)base[row * C + c];
-    s += v;
-    ss += v * v;
+  if ((cpg & 3) == 0 && (C & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+    // 16 bytes per load: a group's channels of one pixel are cpg / 4 consecutive float4
+    const int c4n = cpg >> 2;
+    const int64_t n4 = (int64_t)max(r1 - r0, 0) * c4n;
+    for (int64_t i = threadIdx.x; i < n4; i += 256) {
+      const int64_t row = r0 + i / c4n;
+      const int c = (int)(i % c4n) * 4;
+      const f32x4 v4 = *(const f32x4*)(base + row * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double v = (double)v4[e];
+        s += v;
+        ss += v * v;
+      }
+    }
+  } else {
+    const int64_t n = (int64_t)max(r1 - r0, 0) * cpg;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      const int64_t row = r0 + i / cpg;
+      const int c = (int)(i % cpg);
+      const double v = (double)base[row * C + c];
+      s += v;
+      ss += v * v;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
