@@ -327,20 +327,35 @@ __global__ void gn32_apply_kernel(const float* __restrict__ x, float* __restrict
                                   const float* __restrict__ gamma, const float* __restrict__ beta, int64_t total4,
                                   int HW, int C, int G, int silu) {
   const int cpg = C / G, c4n = C / 4;
+  const bool vec_affine = (cpg & 3) == 0 && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = i / c4n;
     const int c0 = (int)(i - pix * c4n) * 4;
     const int b = (int)(pix / HW);
     const f32x4 v = *(const f32x4*)(x + i * 4);
     f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = c0 + e, g = c / cpg;
+    if (vec_affine) {   // the four channels share a group: one statistics pair, 16-byte scale / shift loads
+      const int g = c0 / cpg;
       const float mean = stats[((int64_t)b * G + g) * 2], rstd = stats[((int64_t)b * G + g) * 2 + 1];
-      float f = (v[e] - mean) * rstd;
-      f = f * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
-      if (silu) f = f / (1.0f + expf(-f));
-      o[e] = f;
+      const f32x4 g4 = gamma ? *(const f32x4*)(gamma + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 b4 = beta ? *(const f32x4*)(beta + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float f = (v[e] - mean) * rstd;
+        f = f * g4[e] + b4[e];
+        if (silu) f = f / (1.0f + expf(-f));
+        o[e] = f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e, g = c / cpg;
+        const float mean = stats[((int64_t)b * G + g) * 2], rstd = stats[((int64_t)b * G + g) * 2 + 1];
+        float f = (v[e] - mean) * rstd;
+        f = f * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+        if (silu) f = f / (1.0f + expf(-f));
+        o[e] = f;
+      }
     }
     *(f32x4*)(y + i * 4) = o;
   }
