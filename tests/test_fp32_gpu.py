@@ -80,6 +80,41 @@ def test_f32_k_chunks_split_or_not_same_bits(ops, cuda, case):
     assert rel_l2(cut(split), full) < 2e-6
 
 
+def test_f32_chunked_launch_through_the_c_abi_odd_width(ops, cuda):
+    """lbmk_igemm called as a C caller would, with a caller-owned partial buffer, on a layer whose width is not a multiple
+    of 4 (the finishing pass then works element by element): same bits as the single launch, f64 reference to f32 rounding"""
+    import ctypes as C
+    from lbm_amd._C import IgemmDesc, check, lib
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 70, 6, 1000
+    x = torch.randn(M, K, generator=g).to(cuda)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda)
+
+    def launch(chunks):
+        out = torch.empty(M, N, device=cuda)
+        d = IgemmDesc()
+        d.a, d.w, d.out, d.bias, d.residual = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr(), res.data_ptr()
+        d.M, d.N, d.K, d.Kp, d.Cin, d.a_cs = M, N, K, K, K, K
+        d.IH = d.IW = d.OH = d.OW = d.KH = d.KW = d.stride = 1
+        d.ldo, d.ldr, d.act, d.out_f32, d.in_f32, d.alpha, d.batch, d.tile = N, N, ops.ACT_SILU, 1, 1, 0.5, 1, -1
+        part = None
+        if chunks:
+            d.f32_chunks = lib.lbmk_igemm_f32_chunks(K, N, 1)
+            part = torch.empty(d.f32_chunks * M * N, device=cuda)
+            d.f32_part = part.data_ptr()
+        check(lib.lbmk_igemm(C.byref(d), torch.cuda.current_stream().cuda_stream), "lbmk_igemm")
+        torch.cuda.synchronize()
+        return out
+
+    assert lib.lbmk_igemm_f32_chunks(K, N, 1) == 8 and lib.lbmk_igemm_f32_split_pays(M, N, K, 1, 1) == 1
+    split, single = launch(True), launch(False)
+    assert torch.equal(split, single)
+    ref = F.silu(0.5 * (x.double() @ w.double().t()) + b.double() + res.double())
+    assert rel_l2(split, ref) < 2e-6
+
+
 def test_linear_geglu_gemm_f32(ops, cuda):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(3, 50, 72, generator=g)
