@@ -21,8 +21,8 @@ torch.cuda.synchronize()
 
 seen = collections.OrderedDict()
 orig = ops._igemm
-def patched(desc, alg_flops=None):
-    orig(desc, alg_flops)
+def patched(desc, alg_flops=None, executed=None):
+    orig(desc, alg_flops, executed)
     key = (desc.M, desc.N, desc.K, desc.KH, desc.stride, desc.up2, desc.batch, desc.act, desc.out_f32, 1 if desc.gn_partial else 0, desc.Cin)
     if key not in seen:
         d = _C.IgemmDesc()
@@ -37,10 +37,17 @@ def patched_tn(a, b, out_dtype=torch.float32, out=None, splits=None):
     tn.setdefault(key, [0, a, b])[0] += 1
     return orig_tn(a, b, out_dtype, out, splits)
 ops.gemm_tn = patched_tn
+nn = collections.OrderedDict()
+orig_nn = ops.gemm_nn
+def patched_nn(a, w, splits=None):
+    key = (a.shape[0], a.shape[1], w.shape[1])
+    nn.setdefault(key, [0, a, w])[0] += 1
+    return orig_nn(a, w, splits)
+ops.gemm_nn = patched_nn
 import lbm_amd.autograd as AG
 keep = pipe.fit_step(batch)
 torch.cuda.synchronize()
-ops._igemm = orig; ops.gemm_tn = orig_tn
+ops._igemm = orig; ops.gemm_tn = orig_tn; ops.gemm_nn = orig_nn
 stream = ops._stream()
 rows = []
 for key, (d, count) in seen.items():
@@ -65,6 +72,17 @@ for (M, N, K), (count, a, b) in tn.items():
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 3 * 1e3)
     rows.append({"kind": "gemm_tn", "M": M, "N": N, "K": K, "count": count, "us": round(best, 1), "ms_total": round(best * count / 1e3, 2),
+                 "tflops": round(2.0 * M * N * K / best / 1e6)})
+for (M, N, K), (count, a, w) in nn.items():
+    best = 1e12
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            orig_nn(a, w)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 3 * 1e3)
+    rows.append({"kind": "gemm_nn", "M": M, "N": N, "K": K, "count": count, "us": round(best, 1), "ms_total": round(best * count / 1e3, 2),
                  "tflops": round(2.0 * M * N * K / best / 1e6)})
 rows.sort(key=lambda r: -r["ms_total"])
 print(json.dumps({"total_ms": round(sum(r["ms_total"] for r in rows), 1), "shapes": len(rows)}))
